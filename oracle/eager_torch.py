@@ -1,0 +1,177 @@
+"""Eager-PyTorch restatement of the clair-torch hot path -- TEST INFRASTRUCTURE ONLY.
+
+This is the "reference-equivalent eager path": the same sequence of full-tensor PyTorch operations and
+``torch.autograd.grad`` calls the reference performs (float32 images, float64 exposure times, detached
+streaming state), written against plain tensors instead of DataLoaders.  It is used
+
+* by tests as the oracle for quantities that need autograd (training-step LUT gradients), and
+* by ``bench.py`` as the ``cpu_baseline`` ("port") timed on the host cores.
+
+It is never imported by the product package.  Parity status: pinned against the golden vectors recorded
+from the reference (tests/test_oracle_golden.py).  Citations are file:line in /root/reference.
+"""
+import torch
+
+LOOKUP, LINEAR, CATMULL = "lookup", "linear", "catmull"
+
+
+def icrf_forward(image, lut, mode=LINEAR):
+    """ICRFModelBase.forward (clair_torch/models/base.py:135-226) for image (N,C,H,W), lut (C,L)."""
+    n, c, h, w = image.shape
+    top = lut.shape[1] - 1
+    if mode == LOOKUP:  # base.py:138-158: nearest sample, true per-channel row, no gradient
+        idx = (image * top).round().clamp(0, top).long()
+        chan = torch.arange(c, device=image.device).view(1, c, 1, 1).expand(n, c, h, w)
+        return lut[chan, idx]
+    # base.py:173-176 / 216-219: the row is the flat NCHW position modulo C, not the channel
+    rows = torch.arange(c, device=image.device).repeat(n * h * w)
+
+    def take(ix):
+        return lut[rows, ix.reshape(-1)].reshape(n, c, h, w)
+
+    if mode == LINEAR:  # base.py:160-182
+        s = (image * top).clamp_(0, top)
+        i0 = s.floor().long()
+        i1 = (i0 + 1).clamp_(0, top)
+        fr = s - i0.float()
+        return take(i0) * (1.0 - fr) + take(i1) * fr
+    if mode == CATMULL:  # base.py:184-226
+        s = (image * top).clamp(0, top)
+        i0 = s.floor().long()
+        t = (s - i0.float()).clamp(0, 1)
+        t2 = t * t
+        t3 = t2 * t
+        basis = (-0.5 * t3 + t2 - 0.5 * t, 1.5 * t3 - 2.5 * t2 + 1.0, -1.5 * t3 + 2.0 * t2 + 0.5 * t,
+                 0.5 * t3 - 0.5 * t2)
+        taps = [take((i0 + k).clamp(0, top)) for k in (-1, 0, 1, 2)]
+        return torch.stack([b * g for b, g in zip(basis, taps)], dim=0).sum(dim=0)
+    raise ValueError(f"Unknown interpolation mode {mode}")
+
+
+def gaussian_weight(image, scale=30.0):
+    """gaussian_value_weights, clair_torch/training/losses.py:193-205."""
+    return torch.exp(-scale * (image - 0.5) ** 2)
+
+
+def merge_stack(vals, stds, exposures, lut, mode=LINEAR, use_gauss=True, partition=None):
+    """compute_hdr_image (clair_torch/inference/hdr_merge.py:61-155) without artefact corrections.
+
+    vals (N,C,H,W) f32, stds same or None, exposures (N) f64.  ``partition`` lists the batch sizes.
+    Streaming state follows WBOMean (clair_torch/common/statistics.py:64-109) incl. the per-batch detach.
+    """
+    n = vals.shape[0]
+    partition = [n] if partition is None else list(partition)
+    mean_a, w_a, variance, k = 0.0, 0.0, None, 0
+    for b in partition:
+        x = vals[k:k + b].clone().requires_grad_(stds is not None)
+        sd = None if stds is None else stds[k:k + b]
+        t = exposures[k:k + b].to(torch.float64).view(-1, 1, 1, 1)
+        k += b
+        wts = gaussian_weight(x) if use_gauss else torch.ones_like(x)
+        with torch.set_grad_enabled(stds is not None):
+            y = (icrf_forward(x, lut, mode) if lut is not None else x) / t
+        w_b = wts.sum(dim=0, keepdim=True)
+        m_b = (wts * y).sum(dim=0, keepdim=True) / (w_b + 1e-6)
+        w_t = w_a + w_b
+        mean = mean_a + (w_b / w_t) * (m_b - mean_a)
+        if sd is not None:
+            g = torch.autograd.grad(mean, x, torch.ones_like(mean), retain_graph=False)[0]
+            upd = ((g * sd) ** 2).sum(dim=0, keepdim=True)
+            variance = upd if variance is None else variance + upd
+        mean_a, w_a = mean.detach(), w_t.detach()
+    return mean_a.squeeze(0), (None if variance is None else torch.sqrt(variance.squeeze(0)))
+
+
+def linearize_frame(val, std, lut, mode=LINEAR):
+    """One iteration of linearize_dataset_generator (clair_torch/inference/linearization.py:95-106,132)."""
+    x = val.unsqueeze(0).clone().requires_grad_(std is not None)
+    with torch.set_grad_enabled(std is not None):
+        lin = icrf_forward(x, lut, mode)
+    var = torch.zeros_like(x)
+    if std is not None:
+        g = torch.autograd.grad(lin, x, torch.ones_like(lin))[0]
+        var = var + (g * std.unsqueeze(0)) ** 2
+    return lin.detach().squeeze(0), torch.sqrt(var).detach().squeeze(0)
+
+
+def exposure_pairs(exposures, threshold):
+    """get_valid_exposure_pairs, clair_torch/common/general_functions.py:242-272."""
+    n = exposures.shape[0]
+    ratios = exposures.view(n, 1) / exposures.view(1, n)
+    i, j = torch.triu_indices(n, n, offset=1)
+    r = ratios[i, j]
+    if threshold is not None:
+        keep = r >= threshold
+        i, j, r = i[keep], j[keep], r[keep]
+    return i, j, r
+
+
+def masked_weighted_mean_std(values, weights, mask, eps=1e-8):
+    """weighted_mean_and_std over (H,W) with mask, clair_torch/common/general_functions.py:118-178."""
+    m = mask.to(values.dtype)
+    v = values * m
+    w = weights * m if weights is not None else m
+    total = w.sum(dim=(2, 3), keepdim=True).clamp(min=eps)
+    mean = (v * w).sum(dim=(2, 3), keepdim=True) / total
+    std = torch.sqrt((((v - mean) ** 2) * w).sum(dim=(2, 3), keepdim=True) / total)
+    return mean.squeeze((2, 3)), std.squeeze((2, 3))
+
+
+def linearity_statistics(vals, stds, exposures, lut, mode, ratio_threshold, lo, hi, use_relative, use_unc_weight):
+    """Body shared by train_icrf (clair_torch/training/icrf_training.py:105-136) and measure_linearity
+    (clair_torch/inference/measure_linearity.py:44-72).  ``lut`` may require grad (training) or be None.
+    Returns (ratio, spatial mean (P,C), spatial std, spatial error|None)."""
+    i, j, r = exposure_pairs(exposures.to(torch.float64), ratio_threshold)
+    xi, xj = vals[i], vals[j]
+    mask = (xi >= lo) & (xi <= hi) & (xj >= lo) & (xj <= hi)                  # general_functions.py:302
+    gw = gaussian_weight(xi, 10.0) + gaussian_weight(xj, 10.0)               # losses.py:208-235
+    x = vals.clone().requires_grad_(stds is not None or (lut is not None and lut.requires_grad))
+    lin = icrf_forward(x, lut, mode) if lut is not None else x
+    if stds is not None:
+        g = torch.autograd.grad(lin, x, torch.ones_like(lin), retain_graph=True)[0]
+        lsd = (g * stds).abs()
+    else:
+        lsd = None
+    rr = r.view(-1, 1, 1, 1)
+    li, lj = lin[i], lin[j]
+    expected = lj * rr                                                         # losses.py:41
+    diff = li - expected
+    safe = expected + 1e-6
+    if use_relative:
+        diff = diff / safe
+    loss = diff.abs()
+    err = None
+    if lsd is not None:                                                        # losses.py:50-63
+        si, sj = lsd[i], lsd[j]
+        if use_relative:
+            err = torch.sqrt((si / safe) ** 2 + ((li * sj) / (safe * lj.clamp(min=1e-6))) ** 2 + 1e-6)
+        else:
+            err = torch.sqrt(si ** 2 + (rr * sj) ** 2)
+    weights = torch.zeros_like(loss)                                           # losses.py:93-100
+    if err is not None and use_unc_weight:
+        weights = weights + 1 / (err + 1e-6)
+    weights = weights + gw
+    sp_mean, sp_std = masked_weighted_mean_std(loss, weights, mask)
+    sp_err = None if err is None else masked_weighted_mean_std(err, None, mask)[0]
+    return r, sp_mean, sp_std, sp_err
+
+
+def curve_penalties(curve):
+    """The four per-channel ICRF penalties, clair_torch/training/losses.py:111-190, curve (C,L)."""
+    df = curve[:, 1:] - curve[:, :-1]
+    mono = ((df <= 0).float() * df.pow(2)).sum(dim=1)
+    rng = (torch.relu(-curve) + torch.relu(curve - 1)).sum(dim=1)
+    endp = curve[:, 0] ** 2 + (curve[:, -1] - 1) ** 2
+    smooth = (curve[:, :-2] - 2 * curve[:, 1:-1] + curve[:, 2:]).pow(2).sum(dim=1)
+    return mono, rng, endp, smooth
+
+
+def training_loss(vals, stds, exposures, lut, mode=LINEAR, ratio_threshold=0.25, lo=1 / 255, hi=254 / 255,
+                  use_relative=True, use_unc_weight=False, alpha=1.0, beta=1.0, gamma=1.0, delta=1.0):
+    """Per-channel loss of one train_icrf step (clair_torch/training/icrf_training.py:105-143).
+    Returns (loss (C,), linearity term (C,), spatial (P,C))."""
+    _, sp, _, _ = linearity_statistics(vals, stds, exposures, lut, mode, ratio_threshold, lo, hi, use_relative,
+                                       use_unc_weight)
+    lin_loss = torch.sqrt((sp ** 2).sum(dim=0))
+    mono, rng, endp, smooth = curve_penalties(lut)
+    return lin_loss + alpha * mono + beta * rng + gamma * endp + delta * smooth, lin_loss, sp

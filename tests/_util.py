@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests: golden-fixture access and the parity criteria."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PARTITIONS = {"8": [8], "44": [4, 4], "332": [3, 3, 2]}
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, f"{name}.npz"))
+
+
+def std_for(mode, x, explicit):
+    """Rebuild the std stack of a golden merge/linearize case from its mode name (make_golden.make_stds)."""
+    if mode == "none":
+        return None
+    if mode == "constant":
+        return np.full_like(x, np.float32(0.01))
+    if mode == "multiplier":
+        return x * np.float32(0.05)
+    if mode == "explicit":
+        return explicit
+    raise ValueError(mode)
+
+
+def rel_norm(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def assert_parity(got, ref, rtol=1e-5, norm_tol=1e-5, elem_tol=None, what=""):
+    """SURVEY 8(d) parity criterion: norm-wise relative error <= norm_tol and
+    allclose(rtol, atol = rtol * median|ref|) element-wise (elem_tol overrides rtol for the element test)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert np.all(np.isfinite(got) == np.isfinite(ref)), f"{what}: finiteness differs"
+    fin = np.isfinite(ref)
+    got, ref = got[fin], ref[fin]
+    if ref.size == 0:
+        return
+    rn = rel_norm(got, ref)
+    assert rn <= norm_tol, f"{what}: norm-wise rel error {rn:.3e} > {norm_tol:.1e}"
+    et = rtol if elem_tol is None else elem_tol
+    atol = et * float(np.median(np.abs(ref)))
+    bad = np.abs(got - ref) > et * np.abs(ref) + atol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{ref.size} elements outside rtol={et:.1e}; "
+                           f"worst {np.max(np.abs(got - ref) / (np.abs(ref) + atol)):.3e}")

@@ -1,0 +1,405 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures in tests/golden/*.npz.
+
+TEST INFRASTRUCTURE, build-container only.  This script imports the *reference* implementation
+(samivout/clair-torch, mounted read-only at /root/reference) and records small input -> output
+vectors for every function on the hot path.  The reference cannot travel
+to the GPU box, so only the resulting .npz data files (inputs + expected outputs) are committed.
+
+The reference needs three packages this image lacks (typeguard, cv2, torchvision).  They are only
+used for decorators / file I/O / the dark-field blur, none of which is on the recorded path, so
+they are replaced by in-process stand-in modules registered in ``sys.modules`` below.  All the
+arithmetic that produces the recorded outputs is executed by the reference's own files.
+
+Run:  python tests/golden/make_golden.py            (writes next to this file)
+"""
+import contextlib
+import os
+import sys
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+REFERENCE_ROOT = os.environ.get("CLAIR_REFERENCE_ROOT", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_stand_ins():
+    tg = types.ModuleType("typeguard")
+    tg.typechecked = lambda *a, **k: a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f)
+    tg.TypeCheckError = type("TypeCheckError", (Exception,), {})
+    tg.suppress_type_checks = contextlib.nullcontext
+    sys.modules["typeguard"] = tg
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+
+    class GaussianBlur:  # never reached by the recorded cases
+        def __init__(self, *a, **k):
+            raise NotImplementedError("torchvision is absent in this image")
+
+    tvt.GaussianBlur = GaussianBlur
+    tv.transforms = tvt
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+
+
+_install_stand_ins()
+sys.path.insert(0, REFERENCE_ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from torch.utils.data import DataLoader, Dataset  # noqa: E402
+
+from clair_torch.common.enums import InterpMode  # noqa: E402
+from clair_torch.common.general_functions import (  # noqa: E402
+    get_pairwise_valid_pixel_mask, get_valid_exposure_pairs, normalize_tensor, weighted_mean_and_std,
+    flat_field_mean, flatfield_correction)
+from clair_torch.common.statistics import WBOMean  # noqa: E402
+from clair_torch.datasets.collate import custom_collate  # noqa: E402
+from clair_torch.inference.hdr_merge import compute_hdr_image  # noqa: E402
+from clair_torch.inference.linearization import linearize_dataset_generator  # noqa: E402
+from clair_torch.inference.measure_linearity import measure_linearity  # noqa: E402
+from clair_torch.models.icrf_model import ICRFModelDirect  # noqa: E402
+from clair_torch.training import losses as ref_losses  # noqa: E402
+from clair_torch.training.icrf_training import train_icrf  # noqa: E402
+
+torch.set_num_threads(4)
+MODES = {"lookup": InterpMode.LOOKUP, "linear": InterpMode.LINEAR, "catmull": InterpMode.CATMULL}
+
+
+class MemoryStack(Dataset):
+    """In-memory stand-in for ImageMapDataset: yields the reference's 4-tuple."""
+
+    def __init__(self, vals, stds, exposures):
+        self.vals, self.stds, self.exposures = vals, stds, exposures
+        self.files = list(range(len(vals)))
+
+    def __len__(self):
+        return len(self.vals)
+
+    def __getitem__(self, i):
+        std = None if self.stds is None else self.stds[i]
+        return i, self.vals[i], std, {"exposure_time": float(self.exposures[i])}
+
+
+def lut_rows(powers, n_points=256):
+    x = torch.linspace(0, 1, n_points)
+    return torch.stack([x ** p for p in powers], dim=0)
+
+
+def synthetic_codes(gen, n, c, h, w, maxcode, exposures):
+    """Gamma-2.2 scene with dark / mid / saturated mix; returns integer codes (N,C,H,W)."""
+    t = torch.tensor(exposures, dtype=torch.float64)
+    t_mid = float(torch.sqrt(t[0] * t[-1]))
+    e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / t_mid)
+    lin = (e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0.0, 1.0)
+    codes = torch.round(lin ** (1 / 2.2) * maxcode)
+    return codes.to(torch.int32)
+
+
+def make_stds(vals, mode, gen):
+    if mode == "none":
+        return None
+    if mode == "constant":
+        s = torch.tensor(0.01)
+        return [s.expand_as(v) for v in vals]
+    if mode == "multiplier":
+        s = torch.tensor(0.05)
+        return [v * s for v in vals]
+    if mode == "explicit":
+        return [0.002 + 0.03 * torch.rand(v.shape, generator=gen) for v in vals]
+    raise ValueError(mode)
+
+
+def partition_loader(ds, partition):
+    """DataLoader honouring an explicit batch partition (shuffle=False order)."""
+    batches, k = [], 0
+    for b in partition:
+        batches.append(list(range(k, k + b)))
+        k += b
+    return DataLoader(ds, batch_sampler=batches, collate_fn=custom_collate)
+
+
+def gen_model_forward(out):
+    gen = torch.Generator().manual_seed(101)
+    lut = lut_rows((1.0, 2.0, 3.0))
+    for name, shape in (("a", (2, 3, 4, 5)), ("b", (3, 3, 5, 7)), ("c", (1, 3, 8, 8))):
+        x = torch.rand(shape, generator=gen)
+        # force exact knots, ends and out-of-range values into the sample
+        flat = x.view(-1)
+        flat[0], flat[1], flat[2], flat[3] = 0.0, 1.0, 100.0 / 255.0, 0.5
+        if name == "c":
+            flat[4], flat[5] = -0.25, 1.5
+        out[f"fwd_{name}_x"] = x.numpy()
+        for mname, mode in MODES.items():
+            model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=mode)
+            with torch.no_grad():
+                out[f"fwd_{name}_{mname}"] = model(x.clone()).numpy()
+    out["fwd_lut"] = lut.numpy()
+    # all integer codes through the normalisation + each mode (index bit-exactness pin)
+    for bits, maxcode in ((8, 255), (16, 65535)):
+        u = torch.arange(maxcode + 1, dtype=torch.float32)
+        x = normalize_tensor(u, max_val=maxcode, min_val=0).view(1, 1, 1, -1).repeat(1, 3, 1, 1)
+        out[f"codes{bits}_x"] = x[0, 0, 0].numpy()
+        for mname, mode in MODES.items():
+            model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=mode)
+            with torch.no_grad():
+                out[f"codes{bits}_{mname}"] = model(x.clone()).numpy()
+
+
+def gen_merge(out):
+    gen = torch.Generator().manual_seed(202)
+    lut = lut_rows((2.2, 2.4, 2.6))
+    out["merge_lut"] = lut.numpy()
+    n, c, h, w = 8, 3, 16, 16
+    exposures = [0.001 * 2.0 ** k for k in range(n)]
+    out["merge_exposures"] = np.asarray(exposures, dtype=np.float64)
+    cases = []
+    for bits, maxcode in ((8, 255), (16, 65535)):
+        codes = synthetic_codes(gen, n, c, h, w, maxcode, exposures)
+        out[f"merge_u{bits}_codes"] = codes.numpy().astype(np.uint16 if bits == 16 else np.uint8)
+        vals = [normalize_tensor(codes[i].float(), max_val=maxcode, min_val=0) for i in range(n)]
+        explicit = make_stds(vals, "explicit", gen)
+        out[f"merge_u{bits}_explicit_std"] = torch.stack(explicit).numpy()
+        for mname in ("linear", "lookup", "catmull", "nomodel"):
+            for wname in ("none", "gauss"):
+                for sname in ("none", "constant", "multiplier", "explicit"):
+                    for pname, partition in (("8", [8]), ("44", [4, 4]), ("332", [3, 3, 2])):
+                        if mname != "linear" and pname == "332":
+                            continue
+                        if mname == "lookup" and wname == "none" and sname != "none":
+                            continue  # reference raises RuntimeError (no grad path); pinned in tests
+                        stds = explicit if sname == "explicit" else make_stds(vals, sname, gen)
+                        ds = MemoryStack([v.clone() for v in vals], stds, exposures)
+                        model = None if mname == "nomodel" else ICRFModelDirect(
+                            icrf=lut.clone(), interpolation_mode=MODES[mname])
+                        wf = None if wname == "none" else ref_losses.gaussian_value_weights
+                        mean, std = compute_hdr_image(partition_loader(ds, partition), "cpu", model, weight_fn=wf)
+                        key = f"merge_u{bits}_{mname}_{wname}_{sname}_{pname}"
+                        out[key + "_mean"] = mean.detach().numpy()
+                        if std is not None:
+                            out[key + "_std"] = std.detach().numpy()
+                        cases.append(key)
+    out["merge_cases"] = np.asarray(cases)
+    # the LOOKUP + no weight + std combination must raise in the reference
+    ds = MemoryStack([v.clone() for v in vals], make_stds(vals, "constant", gen), exposures)
+    model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=InterpMode.LOOKUP)
+    try:
+        compute_hdr_image(partition_loader(ds, [8]), "cpu", model, weight_fn=None)
+        out["merge_lookup_nograd_raises"] = np.asarray(0)
+    except RuntimeError:
+        out["merge_lookup_nograd_raises"] = np.asarray(1)
+
+
+def gen_merge_c1(out):
+    """BASELINE config C1 shape: 8 x 256x256x3 uint8, through the reference on CPU (batch 4 and 8)."""
+    gen = torch.Generator().manual_seed(1234 + 1)
+    lut = lut_rows((2.2, 2.4, 2.6))
+    n, c, h, w = 8, 3, 256, 256
+    exposures = [0.001 * 2.0 ** k for k in range(n)]
+    codes = synthetic_codes(gen, n, c, h, w, 255, exposures)
+    vals = [normalize_tensor(codes[i].float(), max_val=255, min_val=0) for i in range(n)]
+    out["c1_codes"] = codes.numpy().astype(np.uint8)
+    out["c1_exposures"] = np.asarray(exposures)
+    out["c1_lut"] = lut.numpy()
+    for pname, partition in (("8", [8]), ("44", [4, 4])):
+        ds = MemoryStack([v.clone() for v in vals], make_stds(vals, "multiplier", gen), exposures)
+        model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=InterpMode.LINEAR)
+        mean, std = compute_hdr_image(partition_loader(ds, partition), "cpu", model,
+                                      weight_fn=ref_losses.gaussian_value_weights)
+        out[f"c1_{pname}_mean"] = mean.detach().numpy()
+        out[f"c1_{pname}_std"] = std.detach().numpy()
+
+
+def gen_linearize(out):
+    gen = torch.Generator().manual_seed(303)
+    lut = lut_rows((2.2, 2.4, 2.6))
+    out["lin_lut"] = lut.numpy()
+    codes = torch.randint(0, 65536, (3, 3, 32, 33), generator=gen, dtype=torch.int32)
+    out["lin_codes"] = codes.numpy().astype(np.uint16)
+    vals = [normalize_tensor(codes[i].float(), max_val=65535, min_val=0) for i in range(3)]
+    for sname in ("none", "multiplier", "explicit"):
+        stds = make_stds(vals, sname, torch.Generator().manual_seed(304))
+        if sname == "explicit":
+            out["lin_explicit_std"] = torch.stack(stds).numpy()
+        for mname, mode in MODES.items():
+            ds = MemoryStack([v.clone() for v in vals], stds, [0.01, 0.02, 0.04])
+            model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=mode)
+            loader = DataLoader(ds, batch_size=1, shuffle=False, collate_fn=custom_collate)
+            lins, sds = [], []
+            if mname == "lookup" and sname != "none":
+                # LOOKUP has no gradient path to the image: the reference raises (pinned in tests)
+                try:
+                    next(iter(linearize_dataset_generator(loader, "cpu", model)))
+                    out["lin_lookup_std_raises"] = np.asarray(0)
+                except RuntimeError:
+                    out["lin_lookup_std_raises"] = np.asarray(1)
+                continue
+            for lin, sd, _meta in linearize_dataset_generator(loader, "cpu", model):
+                lins.append(lin.numpy())
+                sds.append(sd.numpy())
+            out[f"lin_{mname}_{sname}_val"] = np.stack(lins)
+            out[f"lin_{mname}_{sname}_std"] = np.stack(sds)
+
+
+def training_stack(gen, n=6, c=3, h=32, w=32):
+    exposures = [0.002 * 2.0 ** (k / 1.5) for k in range(n)]
+    codes = synthetic_codes(gen, n, c, h, w, 255, exposures)
+    vals = [normalize_tensor(codes[i].float(), max_val=255, min_val=0) for i in range(n)]
+    return exposures, codes, vals
+
+
+def gen_training(out):
+    gen = torch.Generator().manual_seed(404)
+    exposures, codes, vals = training_stack(gen)
+    n = len(vals)
+    out["train_codes"] = codes.numpy().astype(np.uint8)
+    out["train_exposures"] = np.asarray(exposures)
+    lut0 = lut_rows((2.0, 2.3, 2.7))
+    out["train_lut0"] = lut0.numpy()
+    images = torch.stack(vals)
+    exp_t = torch.tensor(exposures, dtype=torch.float64)
+
+    i_idx, j_idx, ratio = get_valid_exposure_pairs(exp_t, 0.25)
+    out["train_i_idx"], out["train_j_idx"], out["train_ratio"] = i_idx.numpy(), j_idx.numpy(), ratio.numpy()
+
+    for sname in ("none", "multiplier"):
+        stds = None if sname == "none" else torch.stack(make_stds(vals, "multiplier", gen))
+        mask = get_pairwise_valid_pixel_mask(images, i_idx, j_idx, stds, val_lower=1 / 255, val_upper=254 / 255)
+        out[f"train_{sname}_mask_popcount"] = mask.sum(dim=(2, 3)).numpy()
+        gw = ref_losses.combined_gaussian_pair_weights(images, i_idx, j_idx)
+        for mname in ("linear", "catmull"):
+            for rel in (True, False):
+                for unc in (True, False):
+                    model = ICRFModelDirect(icrf=lut0.clone(), interpolation_mode=MODES[mname])
+                    # connect the parameters to the curve as train_icrf does after its first step
+                    with torch.no_grad():
+                        for ch in range(3):
+                            model.direct_params[ch].copy_(lut0[ch])
+                    model.update_icrf()
+                    x = images.clone().requires_grad_(True)
+                    lin = model(x)
+                    if stds is not None:
+                        g = torch.autograd.grad(lin, x, torch.ones_like(lin), retain_graph=True)[0]
+                        lin_std = (g * stds).abs()
+                    else:
+                        lin_std = None
+                    pl, pe = ref_losses.pixelwise_linearity_loss(lin, i_idx, j_idx, ratio, lin_std, rel)
+                    sp, sp_std, sp_err = ref_losses.compute_spatial_linearity_loss(pl, pe, gw, mask, unc)
+                    linloss = torch.sqrt((sp ** 2).sum(dim=0))
+                    curve = model.icrf
+                    mono = ref_losses.compute_monotonicity_penalty(curve, per_channel=True)
+                    rng = ref_losses.compute_range_penalty(curve, per_channel=True)
+                    endp = ref_losses.compute_endpoint_penalty(curve, per_channel=True)
+                    smooth = ref_losses.compute_smoothness_penalty(curve, per_channel=True)
+                    loss = linloss + 10.0 * mono + 1.0 * rng + 1.0 * endp + 1.0 * smooth
+                    for ch in range(3):
+                        loss[ch].backward(retain_graph=True)
+                    grads = torch.stack([p.grad for p in model.direct_params])
+                    # gradient of the linearity term alone (what the HIP backward produces)
+                    for p in model.direct_params:
+                        p.grad = None
+                    for ch in range(3):
+                        linloss[ch].backward(retain_graph=True)
+                    lin_grads = torch.stack([p.grad for p in model.direct_params])
+                    key = f"train_{sname}_{mname}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+                    out[key + "_spatial"] = sp.detach().numpy()
+                    out[key + "_spatial_std"] = sp_std.detach().numpy()
+                    if sp_err is not None:
+                        out[key + "_spatial_err"] = sp_err.detach().numpy()
+                    out[key + "_linloss"] = linloss.detach().numpy()
+                    out[key + "_loss"] = loss.detach().numpy()
+                    out[key + "_grad"] = grads.numpy()
+                    out[key + "_lingrad"] = lin_grads.numpy()
+
+    # measure_linearity 4-tuple (thresholds hard-coded in the reference)
+    for sname in ("none", "multiplier"):
+        stds = None if sname == "none" else make_stds(vals, "multiplier", gen)
+        for mname in ("nomodel", "linear"):
+            for rel in (True, False):
+                for unc in (True, False):
+                    ds = MemoryStack([v.clone() for v in vals], stds, exposures)
+                    loader = DataLoader(ds, batch_size=n, shuffle=False, collate_fn=custom_collate)
+                    model = None if mname == "nomodel" else ICRFModelDirect(
+                        icrf=lut0.clone(), interpolation_mode=InterpMode.LINEAR)
+                    r, sp, sp_std, sp_err = measure_linearity(loader, "cpu", unc, rel, model)
+                    key = f"meas_{sname}_{mname}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+                    out[key + "_ratio"], out[key + "_spatial"] = r.numpy(), sp.detach().numpy()
+                    out[key + "_spatial_std"] = sp_std.detach().numpy()
+                    if sp_err is not None:
+                        out[key + "_spatial_err"] = sp_err.detach().numpy()
+
+    # end-to-end train_icrf: a few epochs, per-channel Adam (scripts/run_icrf_model_training.py:49-69)
+    torch.Tensor.get_device = lambda self: self.device  # CPU shim for icrf_training.py:92
+    for sname in ("none", "multiplier"):
+        for unc in (False, True):
+            if sname == "none" and unc:
+                continue
+            stds = None if sname == "none" else make_stds(vals, "multiplier", gen)
+            ds = MemoryStack([v.clone() for v in vals], stds, exposures)
+            loader = DataLoader(ds, batch_size=n, shuffle=False, collate_fn=custom_collate)
+            torch.manual_seed(0)
+            model = ICRFModelDirect(n_points=256, channels=3, interpolation_mode=InterpMode.LINEAR, initial_power=2.5)
+            opts = [torch.optim.Adam(model.channel_params(ch), lr=1e-3, amsgrad=False) for ch in range(3)]
+            with contextlib.redirect_stdout(open(os.devnull, "w")):
+                train_icrf(loader, n, "cpu", model, optimizers=opts, schedulers=None,
+                           use_relative_linearity_loss=True, use_uncertainty_weighting=unc, epochs=5, patience=200,
+                           alpha=10.0, beta=1.0, gamma=1.0, delta=1.0, lower_valid_threshold=1 / 255,
+                           upper_valid_threshold=254 / 255, exposure_ratio_threshold=0.25)
+            key = f"trainloop_{sname}_{'unc' if unc else 'nounc'}"
+            out[key + "_icrf"] = model.icrf.detach().numpy()
+            out[key + "_params"] = torch.stack([p.detach() for p in model.direct_params]).numpy()
+
+
+def gen_helpers(out):
+    """Known answers for the small host-side helpers on the path."""
+    gen = torch.Generator().manual_seed(505)
+    # WBOMean over three ragged batches, weighted and unweighted
+    vals = torch.rand((9, 3, 4, 4), generator=gen, dtype=torch.float64)
+    wts = torch.rand((9, 3, 4, 4), generator=gen, dtype=torch.float64)
+    out["wbo_vals"], out["wbo_wts"] = vals.numpy(), wts.numpy()
+    for weighted in (True, False):
+        h = WBOMean(dim=0)
+        k = 0
+        for b in (4, 3, 2):
+            m = h.update_values(vals[k:k + b], wts[k:k + b] if weighted else None)
+            k += b
+        out[f"wbo_mean_{'w' if weighted else 'u'}"] = m.numpy()
+        out[f"wbo_sumw_{'w' if weighted else 'u'}"] = h.sum_of_weights.numpy()
+    # weighted_mean_and_std with mask
+    v = torch.rand((4, 3, 6, 5), generator=gen, dtype=torch.float64)
+    wt = torch.rand((4, 3, 6, 5), generator=gen, dtype=torch.float64)
+    mk = torch.rand((4, 3, 6, 5), generator=gen) > 0.4
+    mk[0, 0] = False
+    m, s = weighted_mean_and_std(v, weights=wt, mask=mk, dim=(2, 3))
+    out["wms_v"], out["wms_w"], out["wms_mask"] = v.numpy(), wt.numpy(), mk.numpy()
+    out["wms_mean"], out["wms_std"] = m.numpy(), s.numpy()
+    # exposure pairs known answer (reference test_general_functions.py:290-327)
+    i, j, r = get_valid_exposure_pairs(torch.tensor([1.0, 2.0, 4.0]), 0.4)
+    out["pairs_i"], out["pairs_j"], out["pairs_r"] = i.numpy(), j.numpy(), r.numpy()
+    # gaussian weights
+    xs = torch.linspace(0, 1, 33)
+    out["gauss_x"] = xs.numpy()
+    out["gauss_w30"] = ref_losses.gaussian_value_weights(xs).numpy()
+    out["gauss_w10"] = ref_losses.gaussian_value_weights(xs, 10.0).numpy()
+    # flat field helpers
+    ff = 0.5 + 0.5 * torch.rand((1, 3, 12, 10), generator=gen)
+    im = torch.rand((2, 3, 12, 10), generator=gen)
+    fm = flat_field_mean(ff, 1.0)
+    out["ff_flat"], out["ff_img"], out["ff_mean"] = ff.numpy(), im.numpy(), fm.numpy()
+    out["ff_mean_half"] = flat_field_mean(ff, 0.5).numpy()
+    out["ff_corrected"] = flatfield_correction(im, ff, fm).numpy()
+
+
+def main():
+    for name, fn in (("model_forward", gen_model_forward), ("merge", gen_merge), ("merge_c1", gen_merge_c1),
+                     ("linearize", gen_linearize), ("training", gen_training), ("helpers", gen_helpers)):
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()

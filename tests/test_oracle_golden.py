@@ -1,0 +1,227 @@
+"""Pin the oracle (oracle/ct_oracle.c and oracle/eager_torch.py) to vectors recorded from the reference.
+
+The golden files were produced by tests/golden/make_golden.py, which imports the reference itself.
+These tests run on CPU (no GPU needed) and are the "oracle is trustworthy" gate of the parity chain.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ct_oracle as oc
+from oracle import eager_torch as oe
+from _util import PARTITIONS, assert_parity, golden, std_for
+
+MODES = ("lookup", "linear", "catmull")
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_bit_exact(case, mode):
+    g = golden("model_forward")
+    out = oc.icrf_forward(g[f"fwd_{case}_x"], g["fwd_lut"], mode)
+    assert np.array_equal(out, g[f"fwd_{case}_{mode}"])
+    out_e = oe.icrf_forward(torch.from_numpy(g[f"fwd_{case}_x"]), torch.from_numpy(g["fwd_lut"]), mode).numpy()
+    assert np.array_equal(out_e, g[f"fwd_{case}_{mode}"])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_all_codes_bit_exact(bits):
+    """Every uint8 / uint16 code: normalisation and LUT indexing are bit-exact."""
+    g = golden("model_forward")
+    u = np.arange(2 ** bits).astype(np.uint8 if bits == 8 else np.uint16)
+    x = oc.normalize_codes(u)
+    assert np.array_equal(x, g[f"codes{bits}_x"])
+    xx = np.ascontiguousarray(np.broadcast_to(x.reshape(1, 1, 1, -1), (1, 3, 1, x.size)))
+    for mode in MODES:
+        assert np.array_equal(oc.icrf_forward(xx, g["fwd_lut"], mode), g[f"codes{bits}_{mode}"])
+
+
+def _merge_inputs(g, key):
+    _, ub, mname, wname, sname, pname = key.split("_")
+    x = oc.normalize_codes(g[f"merge_{ub}_codes"])
+    sd = std_for(sname, x, g[f"merge_{ub}_explicit_std"])
+    lut = None if mname == "nomodel" else g["merge_lut"]
+    return x, sd, lut, ("linear" if mname == "nomodel" else mname), wname == "gauss", PARTITIONS[pname]
+
+
+# element-wise tolerance of the reference's own float32 autograd noise per interpolation mode
+ELEM_TOL = {"linear": 2e-5, "nomodel": 1e-5, "lookup": 1e-4, "catmull": 1e-4}
+NORM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 1e-5, "catmull": 2e-5}
+
+
+def test_merge_c_oracle_vs_golden():
+    g = golden("merge")
+    t = g["merge_exposures"]
+    keys = [str(k) for k in g["merge_cases"]]
+    assert len(keys) > 100
+    for key in keys:
+        x, sd, lut, mode, gauss, part = _merge_inputs(g, key)
+        mean, std = oc.hdr_merge(x, sd, t, lut, mode, gauss, part)
+        assert_parity(mean, g[key + "_mean"], rtol=1e-6, norm_tol=1e-6, what=key + " mean")
+        if sd is None:
+            assert std is None and key + "_std" not in g
+        else:
+            mname = key.split("_")[2]
+            assert_parity(std, g[key + "_std"], norm_tol=NORM_TOL[mname], elem_tol=ELEM_TOL[mname],
+                          what=key + " std")
+
+
+def test_merge_eager_oracle_vs_golden():
+    g = golden("merge")
+    t = torch.from_numpy(g["merge_exposures"])
+    keys = [str(k) for k in g["merge_cases"] if "_u16_" in str(k)]
+    for key in keys:
+        x, sd, lut, mode, gauss, part = _merge_inputs(g, key)
+        mean, std = oe.merge_stack(torch.from_numpy(x), None if sd is None else torch.from_numpy(sd), t,
+                                   None if lut is None else torch.from_numpy(lut), mode, gauss, part)
+        assert mean.dtype == torch.float64
+        assert_parity(mean.numpy(), g[key + "_mean"], rtol=1e-12, norm_tol=1e-12, what=key + " mean")
+        if sd is not None:
+            assert std.dtype == torch.float32
+            assert_parity(std.numpy(), g[key + "_std"], rtol=1e-6, norm_tol=1e-6, what=key + " std")
+
+
+def test_merge_lookup_without_weight_raises():
+    g = golden("merge")
+    assert int(g["merge_lookup_nograd_raises"]) == 1
+    x = oc.normalize_codes(g["merge_u8_codes"])
+    with pytest.raises(RuntimeError):
+        oc.hdr_merge(x, np.full_like(x, 0.01), g["merge_exposures"], g["merge_lut"], "lookup", False)
+
+
+def test_merge_config1_shape():
+    """BASELINE config C1 (8 x 256x256x3 uint8) recorded from the reference on CPU."""
+    g = golden("merge_c1")
+    x = oc.normalize_codes(g["c1_codes"])
+    sd = x * np.float32(0.05)
+    for pname in ("8", "44"):
+        mean, std = oc.hdr_merge(x, sd, g["c1_exposures"], g["c1_lut"], "linear", True, PARTITIONS[pname])
+        assert_parity(mean, g[f"c1_{pname}_mean"], rtol=1e-6, norm_tol=1e-6, what="c1 mean")
+        assert_parity(std, g[f"c1_{pname}_std"], norm_tol=1e-5, elem_tol=5e-5, what="c1 std")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sname", ["none", "multiplier", "explicit"])
+def test_linearize(mode, sname):
+    g = golden("linearize")
+    x = oc.normalize_codes(g["lin_codes"])
+    sd = std_for(sname, x, g["lin_explicit_std"])
+    if mode == "lookup" and sd is not None:
+        assert int(g["lin_lookup_std_raises"]) == 1
+        with pytest.raises(RuntimeError):
+            oc.linearize_std(x, sd, g["lin_lut"], mode)
+        return
+    lin, so = oc.linearize_std(x, sd, g["lin_lut"], mode)
+    assert np.array_equal(lin, g[f"lin_{mode}_{sname}_val"])          # bit-exact value
+    if mode == "catmull":
+        # the reference's float32 autograd through the cubic basis cancels ~100x: its own noise is ~1e-5
+        assert_parity(so, g[f"lin_{mode}_{sname}_std"], norm_tol=5e-5, elem_tol=5e-4, what="lin std")
+    else:
+        assert np.array_equal(so, g[f"lin_{mode}_{sname}_std"])       # bit-exact uncertainty
+    for f in range(x.shape[0]):
+        le, se = oe.linearize_frame(torch.from_numpy(x[f]), None if sd is None else torch.from_numpy(sd[f]),
+                                    torch.from_numpy(g["lin_lut"]), mode)
+        assert np.array_equal(le.numpy(), g[f"lin_{mode}_{sname}_val"][f])
+        assert np.array_equal(se.numpy(), g[f"lin_{mode}_{sname}_std"][f])
+
+
+def _train_inputs(g, sname):
+    x = oc.normalize_codes(g["train_codes"])
+    sd = None if sname == "none" else x * np.float32(0.05)
+    return x, sd
+
+
+def test_exposure_pairs_known_answers():
+    g = golden("helpers")
+    i, j, r = oc.exposure_pairs([1.0, 2.0, 4.0], 0.4)           # reference test_general_functions.py:290-327
+    assert i.tolist() == [0, 1] and j.tolist() == [1, 2] and r.tolist() == [0.5, 0.5]
+    assert np.array_equal(i, g["pairs_i"]) and np.array_equal(j, g["pairs_j"]) and np.array_equal(r, g["pairs_r"])
+    gt = golden("training")
+    i, j, r = oc.exposure_pairs(gt["train_exposures"], 0.25)
+    assert np.array_equal(i, gt["train_i_idx"]) and np.array_equal(j, gt["train_j_idx"])
+    assert np.array_equal(r, gt["train_ratio"])
+    ie, je, re_ = oe.exposure_pairs(torch.from_numpy(gt["train_exposures"]), 0.25)
+    assert np.array_equal(ie.numpy(), gt["train_i_idx"]) and np.array_equal(re_.numpy(), gt["train_ratio"])
+
+
+@pytest.mark.parametrize("sname", ["none", "multiplier"])
+@pytest.mark.parametrize("rel", [True, False])
+@pytest.mark.parametrize("unc", [True, False])
+def test_pair_statistics_c_oracle(sname, rel, unc):
+    g = golden("training")
+    x, sd = _train_inputs(g, sname)
+    lin, d = oc.icrf_forward(x, g["train_lut0"], "linear", want_derivative=True)
+    lsd = None if sd is None else np.abs(d * sd)
+    i, j, r = oc.exposure_pairs(g["train_exposures"], 0.25)
+    sums = oc.pair_sums(lin, x, lsd, i, j, r, 1 / 255, 254 / 255, rel, unc)
+    assert np.array_equal(sums[..., 4], g[f"train_{sname}_mask_popcount"].astype(np.float64))
+    mean, std, err = oc.spatial_stats(sums, sd is not None)
+    key = f"train_{sname}_linear_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+    assert_parity(mean, g[key + "_spatial"], rtol=1e-6, norm_tol=1e-6, what=key + " spatial")
+    assert_parity(std, g[key + "_spatial_std"], rtol=1e-5, norm_tol=1e-6, what=key + " spatial std")
+    if sd is not None:
+        assert_parity(err, g[key + "_spatial_err"], rtol=1e-6, norm_tol=1e-6, what=key + " spatial err")
+
+
+@pytest.mark.parametrize("sname", ["none", "multiplier"])
+@pytest.mark.parametrize("mode", ["linear", "catmull"])
+@pytest.mark.parametrize("rel", [True, False])
+@pytest.mark.parametrize("unc", [True, False])
+def test_training_step_eager_oracle(sname, mode, rel, unc):
+    """Loss, spatial statistics and LUT gradients of one train_icrf step."""
+    g = golden("training")
+    x, sd = _train_inputs(g, sname)
+    lut = torch.from_numpy(g["train_lut0"]).clone().requires_grad_(True)
+    loss, lin_loss, sp = oe.training_loss(torch.from_numpy(x), None if sd is None else torch.from_numpy(sd),
+                                          torch.from_numpy(g["train_exposures"]), lut, mode, 0.25, 1 / 255, 254 / 255,
+                                          rel, unc, alpha=10.0)
+    key = f"train_{sname}_{mode}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+    assert_parity(sp.detach().numpy(), g[key + "_spatial"], rtol=1e-10, norm_tol=1e-10, what=key)
+    assert_parity(loss.detach().numpy(), g[key + "_loss"], rtol=1e-10, norm_tol=1e-10, what=key)
+    grad = torch.autograd.grad(loss.sum(), lut, retain_graph=True)[0]
+    assert_parity(grad.numpy(), g[key + "_grad"], rtol=1e-5, norm_tol=1e-6, what=key + " grad")
+    lgrad = torch.autograd.grad(lin_loss.sum(), lut)[0]
+    assert_parity(lgrad.numpy(), g[key + "_lingrad"], rtol=1e-5, norm_tol=1e-6, what=key + " lingrad")
+
+
+@pytest.mark.parametrize("sname", ["none", "multiplier"])
+@pytest.mark.parametrize("mname", ["nomodel", "linear"])
+def test_measure_linearity_oracles(sname, mname):
+    g = golden("training")
+    x, sd = _train_inputs(g, sname)
+    lut = None if mname == "nomodel" else g["train_lut0"]
+    for rel in (True, False):
+        for unc in (True, False):
+            key = f"meas_{sname}_{mname}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+            r, sp, sp_std, sp_err = oe.linearity_statistics(
+                torch.from_numpy(x), None if sd is None else torch.from_numpy(sd),
+                torch.from_numpy(g["train_exposures"]), None if lut is None else torch.from_numpy(lut), "linear",
+                0.2, 1 / 255, 254 / 255, rel, unc)
+            assert np.array_equal(r.numpy(), g[key + "_ratio"])
+            assert_parity(sp.detach().numpy(), g[key + "_spatial"], rtol=1e-10, norm_tol=1e-10, what=key)
+            assert_parity(sp_std.detach().numpy(), g[key + "_spatial_std"], rtol=1e-8, norm_tol=1e-10, what=key)
+            if sd is not None:
+                assert_parity(sp_err.detach().numpy(), g[key + "_spatial_err"], rtol=1e-10, norm_tol=1e-10, what=key)
+            # closed-form C oracle on the same case
+            if lut is None:
+                lin, d = x, np.ones_like(x)
+            else:
+                lin, d = oc.icrf_forward(x, lut, "linear", want_derivative=True)
+            lsd = None if sd is None else np.abs(d * sd)
+            i, j, rr = oc.exposure_pairs(g["train_exposures"], 0.2)
+            mean, std, err = oc.spatial_stats(oc.pair_sums(lin, x, lsd, i, j, rr, 1 / 255, 254 / 255, rel, unc),
+                                              sd is not None)
+            assert_parity(mean, g[key + "_spatial"], rtol=1e-6, norm_tol=1e-6, what=key + " C")
+            assert_parity(std, g[key + "_spatial_std"], rtol=1e-5, norm_tol=1e-6, what=key + " C std")
+
+
+def test_gaussian_weights_and_helpers():
+    g = golden("helpers")
+    x = torch.from_numpy(g["gauss_x"])
+    assert np.array_equal(oe.gaussian_weight(x).numpy(), g["gauss_w30"])
+    assert np.array_equal(oe.gaussian_weight(x, 10.0).numpy(), g["gauss_w10"])
+    assert oe.gaussian_weight(torch.tensor(0.5)).item() == 1.0          # reference test_losses.py:10-28
+    m, s = oe.masked_weighted_mean_std(torch.from_numpy(g["wms_v"]), torch.from_numpy(g["wms_w"]),
+                                       torch.from_numpy(g["wms_mask"]))
+    assert_parity(m.numpy(), g["wms_mean"], rtol=1e-12, norm_tol=1e-12)
+    assert_parity(s.numpy(), g["wms_std"], rtol=1e-12, norm_tol=1e-12)
