@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI in include/clair_hip.h.
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this module raises.  The
+library is built in-tree by ``clair_torch_amd.build`` (hipcc, gfx950) and loaded from
+``clair_torch_amd/lib/libclair_hip.so``.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+# include/clair_hip.h constants
+DTYPE_U8, DTYPE_U16, DTYPE_F32 = 0, 1, 2
+INTERP_LOOKUP, INTERP_LINEAR, INTERP_CATMULL, INTERP_NONE = 0, 1, 2, 3
+STD_NONE, STD_CONSTANT, STD_MULTIPLIER, STD_EXPLICIT = 0, 1, 2, 3
+WEIGHT_NONE, WEIGHT_GAUSS = 0, 1
+MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32 = 1, 2, 4
+ERR_NO_GRADIENT_PATH = -4
+
+EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd",
+           "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd")
+
+
+class Geometry(ctypes.Structure):
+    _fields_ = [("channels", ctypes.c_int32), ("h_tile", ctypes.c_int64), ("width", ctypes.c_int64),
+                ("h_global", ctypes.c_int64), ("row_offset", ctypes.c_int64), ("image_stride", ctypes.c_int64)]
+
+
+class Icrf(ctypes.Structure):
+    _fields_ = [("lut_dev", ctypes.c_void_p), ("n_points", ctypes.c_int32), ("interp", ctypes.c_int32)]
+
+
+class PairParams(ctypes.Structure):
+    _fields_ = [("lower", ctypes.c_float), ("upper", ctypes.c_float), ("weight_scale", ctypes.c_float),
+                ("use_relative", ctypes.c_int32), ("use_uncertainty_weighting", ctypes.c_int32),
+                ("std_mode", ctypes.c_int32), ("std_value", ctypes.c_float)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (once) the HIP shared library; raises NativeLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} is missing: build it with `python -m clair_torch_amd.build` (hipcc, gfx950). "
+            "clair_torch_amd has no CPU fallback for its kernels.")
+    lib = ctypes.CDLL(path)
+    vp, i32, i64, f32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
+    gp, ip = ctypes.POINTER(Geometry), ctypes.POINTER(Icrf)
+    lib.ct_abi_version.restype = i32
+    lib.ct_error_string.restype = ctypes.c_char_p
+    lib.ct_error_string.argtypes = [i32]
+    lib.ct_hdr_merge_batch.restype = i32
+    lib.ct_hdr_merge_batch.argtypes = [vp, i32, f32, i32, gp, vp, i32, f32, vp, ip, i32, vp, vp, vp, vp, vp, u32, vp]
+    lib.ct_linearize_std.restype = i32
+    lib.ct_linearize_std.argtypes = [vp, i32, f32, i64, gp, vp, i32, f32, ip, vp, vp, vp]
+    lib.ct_linearize_fwd.restype = i32
+    lib.ct_linearize_fwd.argtypes = [vp, i64, gp, ip, vp, vp]
+    lib.ct_linearize_bwd.restype = i32
+    lib.ct_linearize_bwd.argtypes = [vp, vp, i64, gp, ip, vp, vp, vp]
+    if hasattr(lib, "ct_pair_residual_fwd"):
+        pp = ctypes.POINTER(PairParams)
+        lib.ct_pair_residual_fwd.restype = i32
+        lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, vp, vp]
+        lib.ct_pair_residual_bwd.restype = i32
+        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, vp, vp, vp]
+    if lib.ct_abi_version() != 1:
+        raise NativeLibraryError(f"{path}: ABI version {lib.ct_abi_version()} != 1; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Translate a C status code into the exception type the reference raises at that point."""
+    if rc == 0:
+        return
+    msg = load().ct_error_string(rc).decode()
+    if rc == ERR_NO_GRADIENT_PATH:
+        # torch.autograd.grad's error text in the reference (hdr_merge.py:108, linearization.py:100)
+        raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
+    if rc in (-1, -5):
+        raise ValueError(f"{what}: {msg}")
+    raise NativeLibraryError(f"{what}: {msg} (code {rc})")

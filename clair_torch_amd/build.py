@@ -1,0 +1,52 @@
+"""Build the gfx950 HIP library (clair_torch_amd/lib/libclair_hip.so) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only build container.
+-ffp-contract=off: several float32 expressions must round exactly as the reference's un-fused eager
+PyTorch ops do; the fused multiply-adds the kernels want are spelled __builtin_fmaf explicitly.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libclair_hip.so")
+SOURCES = ["ct_merge.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_api.cpp"]
+HEADERS = ["ct_device.hpp", os.path.join("..", "..", "include", "clair_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps += [os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

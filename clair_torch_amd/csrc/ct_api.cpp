@@ -1,0 +1,55 @@
+// ct_api.cpp -- host-only pieces of the C ABI: version, error strings, normalisation constants.
+#include <math.h>
+#include <mutex>
+
+#include "../../include/clair_hip.h"
+
+extern "C" int ct_abi_version(void) { return CT_ABI_VERSION; }
+
+extern "C" const char *ct_error_string(int code)
+{
+    switch (code) {
+        case CT_OK: return "ok";
+        case CT_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case CT_ERR_UNSUPPORTED: return "unsupported dtype or mode";
+        case CT_ERR_LAUNCH: return "HIP kernel launch failed";
+        case CT_ERR_NO_GRADIENT_PATH: return "no gradient path from the output to the image (reference raises RuntimeError)";
+        case CT_ERR_TOO_LARGE: return "dimension too large for the kernel's indexing";
+    }
+    return "unknown error";
+}
+
+// The reference normalises integer codes with one float32 division u / max_code
+// (clair_torch/common/general_functions.py:377).  The kernels use fma(u, hi, u * lo) with hi + lo ~ 1/max_code;
+// this routine derives the pair and proves on the host, over every code 0..max_code, that the two agree bit
+// for bit.  Returns CT_ERR_UNSUPPORTED if they do not (then the caller must hand in float32 pixels instead).
+extern "C" int ct_norm_constants(float max_code, float *hi, float *lo)
+{
+    static std::mutex mu;
+    static float cached_max = 0.0f, cached_hi = 0.0f, cached_lo = 0.0f;
+    static int cached_rc = CT_ERR_UNSUPPORTED;
+    if (!(max_code >= 1.0f) || max_code > 65535.0f || floorf(max_code) != max_code) return CT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached_max != max_code) {
+        const double rd = 1.0 / (double)max_code;
+        const float h = (float)rd;
+        const float l = (float)(rd - (double)h);
+        int rc = CT_OK;
+        for (int u = 0; u <= (int)max_code; ++u) {
+            const float uf = (float)u;
+            volatile float ref = uf / max_code;
+            volatile float got = fmaf(uf, h, uf * l);
+            if (ref != got) {
+                rc = CT_ERR_UNSUPPORTED;
+                break;
+            }
+        }
+        cached_max = max_code;
+        cached_hi = h;
+        cached_lo = l;
+        cached_rc = rc;
+    }
+    *hi = cached_hi;
+    *lo = cached_lo;
+    return cached_rc;
+}

@@ -1,0 +1,159 @@
+// ct_device.hpp -- device-side building blocks shared by the gfx950 kernels.
+//
+// Everything here is written for CDNA4 only (64-wide wavefronts, 160 KiB LDS per CU); there is no
+// other backend.  Float32 expressions whose rounding must equal the reference's eager float32 ops are
+// written with explicit __fmul_rn/__fadd_rn-free plain operators and the library is compiled with
+// -ffp-contract=off, so the only fused multiply-adds are the ones spelled __builtin_fmaf below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/clair_hip.h"
+
+namespace ct {
+
+constexpr int kBlock = 256;  // 4 wavefronts per workgroup
+
+// ---- pixel value from a stored element ---------------------------------------------------------
+// Integer codes are normalised exactly as the reference's Normalize(0, max_code) on a float32 tensor
+// (clair_torch/common/general_functions.py:359-388): one correctly rounded float32 division u / max_code.
+// fma(u, r_hi, u * r_lo) with r_hi + r_lo = 1/max_code reproduces that division bit for bit for every
+// code (verified exhaustively on the host in ct_norm_constants before a launch uses it).
+struct NormConst {
+    float hi, lo;
+};
+
+template <typename T>
+__device__ __forceinline__ float to_pixel(T v, NormConst nc)
+{
+    if constexpr (sizeof(T) == 4) {
+        return v;
+    } else {
+        const float u = (float)v;
+        return __builtin_fmaf(u, nc.hi, u * nc.lo);
+    }
+}
+
+// ---- LUT staging in LDS ------------------------------------------------------------------------
+// LINEAR : float2 {g[i], g[min(i+1, L-1)]}            -> one ds_read_b64 per sample
+// CATMULL: float4 {g[i-1], g[i], g[i+1], g[i+2]} clamped -> one ds_read_b128 per sample
+// LOOKUP : float  g[i]
+// Rows are `row_pitch_bytes(interp, L)` apart.
+__device__ __host__ __forceinline__ constexpr int lut_entry_bytes(int interp)
+{
+    return interp == CT_INTERP_LINEAR ? 8 : (interp == CT_INTERP_CATMULL ? 16 : 4);
+}
+
+template <int INTERP>
+__device__ __forceinline__ void stage_lut(char *lds, const float *__restrict__ lut, int C, int L)
+{
+    if constexpr (INTERP == CT_INTERP_NONE) {
+        return;
+    } else {
+        const int total = C * L;
+        for (int k = threadIdx.x; k < total; k += blockDim.x) {
+            const int r = k / L, i = k - r * L;
+            const float *row = lut + (size_t)r * L;
+            const int im = i > 0 ? i - 1 : 0, i1 = i + 1 < L ? i + 1 : L - 1, i2 = i + 2 < L ? i + 2 : L - 1;
+            if constexpr (INTERP == CT_INTERP_LINEAR) {
+                reinterpret_cast<float2 *>(lds)[k] = make_float2(row[i], row[i1]);
+            } else if constexpr (INTERP == CT_INTERP_CATMULL) {
+                reinterpret_cast<float4 *>(lds)[k] = make_float4(row[im], row[i], row[i1], row[i2]);
+            } else {
+                reinterpret_cast<float *>(lds)[k] = row[i];
+            }
+        }
+    }
+}
+
+// One sample through the staged LUT.
+//   EXACT   : reproduce the reference's float32 operation order bit for bit (linearize path);
+//             otherwise the lerp is a single FMA (merge path, 1e-5 tolerance).
+//   RANGED  : the value is known to lie in [0,1] (integer codes) -> no clamp, derivative mask = 1.
+// Returns f(x); dfdx receives df/dx (0 for LOOKUP).  `row_lds` points at this element's LUT row.
+template <int INTERP, bool EXACT, bool RANGED>
+__device__ __forceinline__ float icrf_sample(float x, const char *row_lds, float top, float &dfdx)
+{
+    if constexpr (INTERP == CT_INTERP_NONE) {
+        dfdx = 1.0f;
+        return x;
+    } else if constexpr (INTERP == CT_INTERP_LOOKUP) {
+        // clair_torch/models/base.py:146: (image * (L-1)).round().clamp(0, L-1); rintf = half to even
+        float r = rintf(x * top);
+        r = fminf(fmaxf(r, 0.0f), top);
+        dfdx = 0.0f;
+        return reinterpret_cast<const float *>(row_lds)[(int)r];
+    } else {
+        const float sraw = x * top;  // base.py:166 / 190
+        float s = sraw, pass = 1.0f;
+        if constexpr (!RANGED) {
+            s = fminf(fmaxf(sraw, 0.0f), top);
+            pass = (sraw >= 0.0f && sraw <= top) ? 1.0f : 0.0f;  // clamp backward mask
+        }
+        const float fl = floorf(s);
+        const int i0 = (int)fl;
+        const float fr = s - fl;  // base.py:170 (exact: Sterbenz)
+        if constexpr (INTERP == CT_INTERP_LINEAR) {
+            const float2 g = reinterpret_cast<const float2 *>(row_lds)[i0];
+            const float dg = g.y - g.x;
+            dfdx = dg * top;
+            if constexpr (!RANGED) dfdx *= pass;
+            if constexpr (EXACT) {
+                const float a = g.x * (1.0f - fr);  // base.py:182: g0 * (1 - w) + g1 * w, un-fused
+                const float b = g.y * fr;
+                return a + b;
+            } else {
+                return __builtin_fmaf(dg, fr, g.x);
+            }
+        } else {  // CATMULL, base.py:184-226
+            const float4 g = reinterpret_cast<const float4 *>(row_lds)[i0];
+            const float t = fr;  // already in [0,1)
+            const float t2 = t * t, t3 = t2 * t;
+            const float w0 = -0.5f * t3 + t2 - 0.5f * t;
+            const float w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
+            const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * t;
+            const float w3 = 0.5f * t3 - 0.5f * t2;
+            float r = w0 * g.x;
+            r = r + w1 * g.y;
+            r = r + w2 * g.z;
+            r = r + w3 * g.w;
+            // derivative of the basis in t, chained through s = x * (L-1)
+            const float d0 = __builtin_fmaf(__builtin_fmaf(-1.5f, t, 2.0f), t, -0.5f);
+            const float d1 = __builtin_fmaf(4.5f, t, -5.0f) * t;
+            const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
+            const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
+            // sum (g_k - g_1) d_k: the d_k sum to zero, subtracting g_1 removes the ~100x cancellation
+            const float acc = __builtin_fmaf(d0, g.x - g.y, __builtin_fmaf(d2, g.z - g.y, d3 * (g.w - g.y)));
+            (void)d1;
+            dfdx = acc * top;
+            if constexpr (!RANGED) dfdx *= pass;
+            return r;
+        }
+    }
+}
+
+// Which LUT row the reference uses for the element with GLOBAL in-image flat index q (= (c*H + h)*W + w):
+// LOOKUP uses the channel (base.py:149-155); LINEAR / CATMULL use flat_index % C (base.py:173-176, 216-219),
+// and n*C*H*W is a multiple of C so the exposure index drops out.
+template <int INTERP>
+__device__ __forceinline__ int lut_row(uint32_t q_global, int channel, int C)
+{
+    if constexpr (INTERP == CT_INTERP_LOOKUP)
+        return channel;
+    else
+        return (int)(q_global % (uint32_t)C);
+}
+
+// Tile geometry -> global flat index of local element ql (see ct_geometry in clair_hip.h).
+struct TileMap {
+    uint32_t plane_local;  // H_tile * W
+    uint32_t chan_skip;    // (H_global - H_tile) * W
+    uint32_t base;         // row_offset * W
+    __device__ __forceinline__ void locate(uint32_t ql, int &channel, uint32_t &q_global) const
+    {
+        channel = (int)(ql / plane_local);
+        q_global = ql + (uint32_t)channel * chan_skip + base;
+    }
+};
+
+}  // namespace ct

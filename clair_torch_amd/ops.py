@@ -1,0 +1,207 @@
+"""Tensor-level front-end of the HIP kernels (thin: validation, pointer plumbing, stream selection).
+
+PyTorch is used here only for device memory, streams and dtype bookkeeping; all arithmetic on image
+data happens inside the C-ABI library (include/clair_hip.h).  Every function requires CUDA (ROCm) tensors
+and raises otherwise -- there is no CPU implementation in this package.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _native as nv
+
+_INTERP = {"lookup": nv.INTERP_LOOKUP, "linear": nv.INTERP_LINEAR, "catmull": nv.INTERP_CATMULL, None: nv.INTERP_NONE}
+_STD = {"none": nv.STD_NONE, "constant": nv.STD_CONSTANT, "multiplier": nv.STD_MULTIPLIER, "explicit": nv.STD_EXPLICIT}
+_DTYPE = {torch.uint8: nv.DTYPE_U8, torch.uint16: nv.DTYPE_U16, torch.float32: nv.DTYPE_F32}
+
+
+@dataclass
+class TileGeometry:
+    """Rows [row_offset, row_offset + h_tile) of a global (C, h_global, W) image (include/clair_hip.h ct_geometry)."""
+    h_global: int
+    row_offset: int = 0
+
+
+def _require_device(t: torch.Tensor, name: str):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: clair_torch_amd kernels run on MI355X (cuda/ROCm) tensors only; "
+                           "there is no CPU path in this package")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _geometry(stack: torch.Tensor, tile: Optional[TileGeometry]) -> nv.Geometry:
+    _, c, h, w = stack.shape
+    hg, r0 = (h, 0) if tile is None else (tile.h_global, tile.row_offset)
+    if r0 < 0 or r0 + h > hg:
+        raise ValueError(f"tile rows [{r0}, {r0 + h}) do not fit a global height of {hg}")
+    return nv.Geometry(channels=c, h_tile=h, width=w, h_global=hg, row_offset=r0, image_stride=stack.stride(0))
+
+
+def _check_stack(stack: torch.Tensor, name="stack"):
+    _require_device(stack, name)
+    if stack.ndim != 4:
+        raise ValueError(f"{name} must be (N, C, H, W), got shape {tuple(stack.shape)}")
+    if stack.dtype not in _DTYPE:
+        raise TypeError(f"{name} dtype {stack.dtype} unsupported (uint8, uint16 codes or float32 pixels)")
+    if stack.shape[0] > 0 and not stack[0].is_contiguous():
+        raise ValueError(f"every image of {name} must be contiguous (C, H, W)")
+
+
+def _icrf_struct(lut: Optional[torch.Tensor], interp, channels):
+    if lut is None:
+        return nv.Icrf(lut_dev=None, n_points=0, interp=nv.INTERP_NONE), None
+    _require_device(lut, "lut")
+    if lut.ndim != 2 or lut.shape[0] != channels:
+        raise ValueError(f"lut must be (C={channels}, L), got {tuple(lut.shape)}")
+    if interp not in _INTERP or interp is None:
+        raise ValueError(f"Unknown interpolation mode {interp}")
+    lut_c = lut.detach().to(torch.float32).contiguous()
+    return nv.Icrf(lut_dev=lut_c.data_ptr(), n_points=lut_c.shape[1], interp=_INTERP[interp]), lut_c
+
+
+class MergeState:
+    """Device-resident WBOMean state + running variance of a streaming merge (one entry per output element)."""
+
+    def __init__(self, shape, device, with_variance: bool):
+        self.mean = torch.empty(shape, dtype=torch.float64, device=device)
+        self.sumw = torch.empty(shape, dtype=torch.float32, device=device)
+        self.var = torch.empty(shape, dtype=torch.float32, device=device) if with_variance else None
+        self.batches = 0
+
+
+def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Optional[torch.Tensor] = None,
+                    interp: Optional[str] = "linear", gaussian_weight: bool = True,
+                    std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
+                    max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
+                    tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64):
+    """One batch of the HDR merge (ct_hdr_merge_batch).  Returns (mean, std|None) when ``finalize`` else None.
+
+    stack (B,C,H,W) uint8/uint16 codes (give ``max_code``) or float32 pixels; exposures (B) any float dtype.
+    ``state`` carries the streaming state across batches (None = single-batch merge).
+    """
+    _check_stack(stack)
+    b, c, h, w = stack.shape
+    dev = stack.device
+    if b < 1:
+        raise ValueError("empty batch")
+    if std is not None:
+        std_mode = "explicit"
+        _require_device(std, "std")
+        if std.shape != stack.shape or std.dtype != torch.float32 or std.stride() != stack.stride():
+            if std.shape != stack.shape:
+                raise ValueError(f"std shape {tuple(std.shape)} != stack shape {tuple(stack.shape)}")
+            std = std.to(torch.float32).contiguous()
+            if std.stride() != stack.stride():
+                stack = stack.contiguous()
+    if std_mode not in _STD:
+        raise ValueError(f"unknown std_mode {std_mode}")
+    if stack.dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
+    exposure_dev = exposures.to(device=dev, dtype=torch.float64).contiguous()
+    if exposure_dev.numel() != b:
+        raise ValueError(f"{exposure_dev.numel()} exposure times for a batch of {b}")
+    icrf, lut_keep = _icrf_struct(lut, interp, c)
+    geom = _geometry(stack, tile)
+    has_std = std_mode != "none"
+    first = state is None or state.batches == 0
+    flags = (nv.MERGE_FIRST_BATCH if first else 0) | (nv.MERGE_FINALIZE if finalize else 0)
+    if mean_dtype == torch.float32:
+        flags |= nv.MERGE_MEAN_OUT_F32
+    elif mean_dtype != torch.float64:
+        raise TypeError("mean_dtype must be float64 (reference) or float32")
+    if state is None and not finalize:
+        raise ValueError("a non-final batch needs a MergeState")
+    if state is not None and has_std and state.var is None:
+        raise ValueError("MergeState was created without a variance buffer")
+    mean_out = torch.empty((c, h, w), dtype=mean_dtype, device=dev) if finalize else None
+    std_out = torch.empty((c, h, w), dtype=torch.float32, device=dev) if (finalize and has_std) else None
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_hdr_merge_batch(
+            _ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), b, ctypes.byref(geom), _ptr(std), _STD[std_mode],
+            float(std_value), _ptr(exposure_dev), ctypes.byref(icrf), nv.WEIGHT_GAUSS if gaussian_weight else nv.WEIGHT_NONE,
+            _ptr(state.mean) if state else None, _ptr(state.sumw) if state else None,
+            _ptr(state.var) if (state and state.var is not None) else None, _ptr(mean_out), _ptr(std_out), flags,
+            _stream(dev))
+    nv.check(rc, "ct_hdr_merge_batch")
+    del lut_keep
+    if state is not None:
+        state.batches += 1
+    return (mean_out, std_out) if finalize else None
+
+
+def linearize_frames(frames: torch.Tensor, lut: torch.Tensor, interp: str = "linear", *,
+                     std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
+                     max_code: Optional[float] = None, want_std: bool = True, tile: Optional[TileGeometry] = None):
+    """ct_linearize_std on (F,C,H,W) frames -> (lin float32, std float32 | None); every frame is its own batch."""
+    _check_stack(frames, "frames")
+    f, c, h, w = frames.shape
+    dev = frames.device
+    if std is not None:
+        std_mode = "explicit"
+        _require_device(std, "std")
+        if std.shape != frames.shape:
+            raise ValueError("std shape != frames shape")
+        std = std.to(torch.float32).contiguous()
+        frames = frames.contiguous()
+    if frames.dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if frames.dtype == torch.uint8 else 65535.0
+    icrf, lut_keep = _icrf_struct(lut, interp, c)
+    geom = _geometry(frames, tile)
+    lin = torch.empty((f, c, h, w), dtype=torch.float32, device=dev)
+    if lin.stride(0) != frames.stride(0):
+        frames = frames.contiguous()
+        geom = _geometry(frames, tile)
+    std_out = torch.empty_like(lin) if want_std else None
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_linearize_std(_ptr(frames), _DTYPE[frames.dtype], float(max_code or 1.0), f, ctypes.byref(geom),
+                                        _ptr(std), _STD[std_mode], float(std_value), ctypes.byref(icrf), _ptr(lin),
+                                        _ptr(std_out), _stream(dev))
+    nv.check(rc, "ct_linearize_std")
+    del lut_keep
+    return lin, std_out
+
+
+def icrf_forward(x: torch.Tensor, lut: torch.Tensor, interp: str, tile: Optional[TileGeometry] = None):
+    """ct_linearize_fwd: ICRFModelBase.forward on a float32 (N,C,H,W) device tensor."""
+    _check_stack(x, "image")
+    if x.dtype != torch.float32:
+        raise TypeError("icrf_forward expects float32 pixel values")
+    x = x.contiguous()
+    icrf, lut_keep = _icrf_struct(lut, interp, x.shape[1])
+    geom = _geometry(x, tile)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = nv.load().ct_linearize_fwd(_ptr(x), x.shape[0], ctypes.byref(geom), ctypes.byref(icrf), _ptr(out),
+                                        _stream(x.device))
+    nv.check(rc, "ct_linearize_fwd")
+    del lut_keep
+    return out
+
+
+def icrf_backward(x: torch.Tensor, grad_out: torch.Tensor, lut: torch.Tensor, interp: str, need_x: bool, need_lut: bool,
+                  tile: Optional[TileGeometry] = None):
+    """ct_linearize_bwd: (grad wrt image | None, grad wrt LUT (C,L) | None)."""
+    _check_stack(x, "image")
+    x = x.contiguous()
+    grad_out = grad_out.to(torch.float32).contiguous()
+    icrf, lut_keep = _icrf_struct(lut, interp, x.shape[1])
+    geom = _geometry(x, tile)
+    gx = torch.empty_like(x) if need_x else None
+    gl = torch.zeros((x.shape[1], lut.shape[1]), dtype=torch.float32, device=x.device) if need_lut else None
+    with torch.cuda.device(x.device):
+        rc = nv.load().ct_linearize_bwd(_ptr(x), _ptr(grad_out), x.shape[0], ctypes.byref(geom), ctypes.byref(icrf),
+                                        _ptr(gx), _ptr(gl), _stream(x.device))
+    nv.check(rc, "ct_linearize_bwd")
+    del lut_keep
+    return gx, gl

@@ -1,0 +1,134 @@
+/*
+ * clair_hip.h -- C ABI of the MI355X (gfx950) implementation of clair-torch's per-pixel hot path.
+ *
+ * The reference (samivout/clair-torch) is pure Python on eager PyTorch and has no FFI of its own; each entry
+ * point below replaces the *interior* of one reference function (file:line cited per function, relative to
+ * the reference repository).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no torch / HIP types in the signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - every pointer named *_dev is DEVICE memory owned by the caller; nothing is allocated, freed or retained;
+ *   - launches are asynchronous on `stream`; no hidden device synchronisation; re-entrant across streams;
+ *   - return value: CT_OK (0) or a negative CT_ERR_* code; never throws.  ct_error_string() names a code.
+ *   - image stacks are NCHW, contiguous inside one exposure; consecutive exposures are `image_stride`
+ *     elements apart (= C*H_tile*W for a dense stack).
+ *
+ * Tiling (multi-GPU row bands): a rank holds rows [row_offset, row_offset + H_tile) of every channel plane of a
+ * global (C, H_global, W) image.  The reference picks the LUT row for LINEAR/CATMULL interpolation from the flat
+ * NCHW index modulo C (clair_torch/models/base.py:173-176, 216-219), so kernels need the GLOBAL geometry to
+ * reproduce it on a tile; pass H_global = H_tile and row_offset = 0 for an untiled image.
+ */
+#ifndef CLAIR_HIP_H
+#define CLAIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT_ABI_VERSION 1
+
+/* status codes */
+#define CT_OK 0
+#define CT_ERR_INVALID_ARGUMENT (-1)
+#define CT_ERR_UNSUPPORTED (-2)      /* dtype / mode combination not built */
+#define CT_ERR_LAUNCH (-3)           /* HIP launch failure */
+#define CT_ERR_NO_GRADIENT_PATH (-4) /* the reference raises RuntimeError here (no grad path to the image) */
+#define CT_ERR_TOO_LARGE (-5)        /* a dimension exceeds what the kernels index */
+
+/* element type of an image stack */
+#define CT_DTYPE_U8 0  /* raw codes; x = code / max_code exactly as Normalize(0, max_code) on float32 */
+#define CT_DTYPE_U16 1
+#define CT_DTYPE_F32 2 /* already normalised float32 pixel values */
+
+/* clair_torch/common/enums.py:10 InterpMode (+ "no model": icrf_model=None) */
+#define CT_INTERP_LOOKUP 0
+#define CT_INTERP_LINEAR 1
+#define CT_INTERP_CATMULL 2
+#define CT_INTERP_NONE 3
+
+/* where the standard uncertainty of a sample comes from (clair_torch/datasets/base.py:128-135 MissingStdMode) */
+#define CT_STD_NONE 0       /* no uncertainty propagated */
+#define CT_STD_CONSTANT 1   /* sigma = std_value */
+#define CT_STD_MULTIPLIER 2 /* sigma = std_value * x */
+#define CT_STD_EXPLICIT 3   /* sigma read from std_dev (float32, same layout as the stack) */
+
+/* weight_fn of compute_hdr_image: None -> ones, anything else -> Gaussian scale 30 (hdr_merge.py:95) */
+#define CT_WEIGHT_NONE 0
+#define CT_WEIGHT_GAUSS 1
+
+/* flags of ct_hdr_merge_batch */
+#define CT_MERGE_FIRST_BATCH 1u  /* state is not read (WBOMean starts at mean 0, weight 0) */
+#define CT_MERGE_FINALIZE 2u     /* also write mean_out / std_out = sqrt(variance) after this batch */
+#define CT_MERGE_MEAN_OUT_F32 4u /* mean_out is float32 instead of the reference's float64 */
+
+/* Geometry of a (tile of a) stack. */
+typedef struct ct_geometry {
+    int32_t channels;     /* C */
+    int64_t h_tile;       /* rows held locally */
+    int64_t width;        /* W */
+    int64_t h_global;     /* rows of the full image (== h_tile when untiled) */
+    int64_t row_offset;   /* first global row held locally */
+    int64_t image_stride; /* elements between consecutive exposures / frames */
+} ct_geometry;
+
+/* ICRF model: LUT (C, L) float32 row-major as ICRFModelBase._icrf (clair_torch/models/base.py:69-71). */
+typedef struct ct_icrf {
+    const float *lut_dev; /* NULL with interp == CT_INTERP_NONE */
+    int32_t n_points;     /* L */
+    int32_t interp;       /* CT_INTERP_* */
+} ct_icrf;
+
+/* library / ABI */
+int ct_abi_version(void);
+const char *ct_error_string(int code);
+
+/*
+ * ct_hdr_merge_batch -- one batch of compute_hdr_image's loop body
+ * (clair_torch/inference/hdr_merge.py:61-128: linearize, / exposure, weights, WBOMean.update_values
+ *  [clair_torch/common/statistics.py:64-109], autograd variance [hdr_merge.py:107-115], internal_detach)
+ * fused into one pass over the batch; with CT_MERGE_FINALIZE also hdr_merge.py:155 (squeeze + sqrt).
+ *
+ *   stack_dev      (B, C, H_tile, W) of `dtype`, exposures sorted as custom_collate does (datasets/collate.py:23)
+ *   max_code       255 / 65535 / ... for integer dtypes (ignored for CT_DTYPE_F32)
+ *   std_dev        explicit float32 std stack (CT_STD_EXPLICIT) else NULL; std_value for CONSTANT / MULTIPLIER
+ *   exposure_dev   (B) float64 exposure times (collate.py:29 makes them float64)
+ *   mean_state_dev (Q) float64, sumw_state_dev (Q) float32, var_state_dev (Q) float32, Q = C*H_tile*W:
+ *                  WBOMean state + running variance, updated in place; may all be NULL when flags has both
+ *                  FIRST_BATCH and FINALIZE (single-batch merge)
+ *   mean_out_dev   (Q) float64 (or float32 with CT_MERGE_MEAN_OUT_F32), std_out_dev (Q) float32 or NULL when
+ *                  std_mode == CT_STD_NONE; written only with CT_MERGE_FINALIZE
+ * Returns CT_ERR_NO_GRADIENT_PATH for LOOKUP + CT_WEIGHT_NONE + std (the reference's autograd.grad raises).
+ */
+int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int32_t batch, const ct_geometry *geom,
+                       const float *std_dev, int32_t std_mode, float std_value, const double *exposure_dev,
+                       const ct_icrf *icrf, int32_t weight_mode, double *mean_state_dev, float *sumw_state_dev,
+                       float *var_state_dev, void *mean_out_dev, float *std_out_dev, uint32_t flags, void *stream);
+
+/*
+ * ct_linearize_std -- body of linearize_dataset_generator for F independent frames
+ * (clair_torch/inference/linearization.py:95-106,132): lin = f(x), std = sqrt((f'(x) * sigma)^2), float32,
+ * bit-exact with the reference for LOOKUP / LINEAR.  std_out_dev may be NULL (value only).
+ * Each frame is its own batch of one, as the reference requires (linearization.py:42).
+ */
+int ct_linearize_std(const void *frames_dev, int32_t dtype, float max_code, int64_t n_frames, const ct_geometry *geom,
+                     const float *std_dev, int32_t std_mode, float std_value, const ct_icrf *icrf, float *lin_out_dev,
+                     float *std_out_dev, void *stream);
+
+/*
+ * ct_linearize_fwd / ct_linearize_bwd -- ICRFModelBase.forward (clair_torch/models/base.py:135-226) on a
+ * (N, C, H_tile, W) float32 tensor and its backward: grad wrt the image (analytic derivative of the LUT
+ * interpolation incl. the clamp mask) and, when lut_grad_dev != NULL, the (C, L) float32 LUT gradient
+ * accumulated (+=) with LDS-privatised scatter.  Used by the model's autograd wrapper.
+ */
+int ct_linearize_fwd(const float *x_dev, int64_t n_images, const ct_geometry *geom, const ct_icrf *icrf,
+                     float *out_dev, void *stream);
+int ct_linearize_bwd(const float *x_dev, const float *grad_out_dev, int64_t n_images, const ct_geometry *geom,
+                     const ct_icrf *icrf, float *grad_x_dev, float *lut_grad_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAIR_HIP_H */
