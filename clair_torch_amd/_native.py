@@ -71,12 +71,12 @@ def load():
     lib.ct_linearize_fwd.argtypes = [vp, i64, gp, ip, vp, vp]
     lib.ct_linearize_bwd.restype = i32
     lib.ct_linearize_bwd.argtypes = [vp, vp, i64, gp, ip, vp, vp, vp]
-    if hasattr(lib, "ct_pair_residual_fwd"):
+    if True:
         pp = ctypes.POINTER(PairParams)
         lib.ct_pair_residual_fwd.restype = i32
-        lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, vp, vp]
+        lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, i32, vp, vp, vp]
         lib.ct_pair_residual_bwd.restype = i32
-        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, vp, vp, vp]
+        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp]
     if lib.ct_abi_version() != 1:
         raise NativeLibraryError(f"{path}: ABI version {lib.ct_abi_version()} != 1; rebuild the library")
     _lib = lib

@@ -3,6 +3,8 @@
 hipcc cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only build container.
 -ffp-contract=off: several float32 expressions must round exactly as the reference's un-fused eager
 PyTorch ops do; the fused multiply-adds the kernels want are spelled __builtin_fmaf explicitly.
+-fno-slp-vectorize: packed float32 VALU ops (v_pk_*_f32) that SLP forms are slower than the scalar ops
+they replace on gfx950 for these kernels (measured 10 % on the merge kernel, tools/merge_variants.hip).
 """
 import os
 import shutil
@@ -16,7 +18,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libclair_hip.so")
 SOURCES = ["ct_merge.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_api.cpp"]
 HEADERS = ["ct_device.hpp", os.path.join("..", "..", "include", "clair_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+         "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
 
 def _hipcc():

@@ -53,3 +53,44 @@ extern "C" int ct_norm_constants(float max_code, float *hi, float *lo)
     *lo = cached_lo;
     return cached_rc;
 }
+
+// Folded LUT coordinate for integer codes: s = fma(u, hi, u * lo) with hi + lo ~ (L-1) / max_code, i.e. the correctly
+// rounded u * (L-1) / max_code, instead of the reference's two roundings fl(fl(u / max_code) * (L-1))
+// (clair_torch/models/base.py:166).  The interpolation interval floor(s) (and round-half-even(s) for LOOKUP) selects
+// which LUT samples -- and which derivative -- a pixel uses, so the fold is only allowed when both agree with the
+// reference's float32 arithmetic for EVERY code; this routine checks that exhaustively (<= 65536 codes) and caches
+// the verdict per (max_code, L).
+extern "C" int ct_index_constants(float max_code, int n_points, float *hi, float *lo)
+{
+    static std::mutex mu;
+    static float cached_max = 0.0f, cached_hi = 0.0f, cached_lo = 0.0f;
+    static int cached_L = 0, cached_rc = CT_ERR_UNSUPPORTED;
+    if (!(max_code >= 1.0f) || max_code > 65535.0f || floorf(max_code) != max_code || n_points < 2)
+        return CT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached_max != max_code || cached_L != n_points) {
+        const float top = (float)(n_points - 1);
+        const double rd = (double)top / (double)max_code;
+        const float h = (float)rd;
+        const float l = (float)(rd - (double)h);
+        int rc = CT_OK;
+        for (int u = 0; u <= (int)max_code; ++u) {
+            const float uf = (float)u;
+            volatile float x = uf / max_code;
+            volatile float s_ref = x * top;
+            volatile float s_new = fmaf(uf, h, uf * l);
+            if (floorf(s_ref) != floorf(s_new) || nearbyintf(s_ref) != nearbyintf(s_new) || s_new > top || s_new < 0.0f) {
+                rc = CT_ERR_UNSUPPORTED;
+                break;
+            }
+        }
+        cached_max = max_code;
+        cached_L = n_points;
+        cached_hi = h;
+        cached_lo = l;
+        cached_rc = rc;
+    }
+    *hi = cached_hi;
+    *lo = cached_lo;
+    return cached_rc;
+}

@@ -40,10 +40,11 @@ struct MergeArgs {
     uint32_t q_count;      // number of local elements handled by this launch (multiple of V)
     TileMap tile;
     int32_t batch, channels, n_points;
-    NormConst norm;
+    NormConst norm;       // code -> pixel (un-folded path)
+    NormConst index;      // code -> LUT coordinate s = u * (L-1) / max_code (folded path)
+    float inv_max_code;   // 1 / max_code (1 for float input)
     float std_value;
-    float neg_scale_log2e;  // -scale * log2(e)
-    float neg_two_scale;    // -2 * scale
+    float weight_scale;   // Gaussian scale (30)
     uint32_t flags;
 };
 
@@ -52,25 +53,42 @@ struct alignas(sizeof(T) * V) Packet {
     T v[V];
 };
 
-template <typename T, int V, int INTERP, int WEIGHT, int STD>
+// Arithmetic of one sample, written so that every constant factor is folded out of the loop:
+//   dk  = kk (x - 1/2),  kk = sqrt(scale log2 e)          w = exp2(-dk^2)            (= exp(-scale (x-1/2)^2))
+//   av  = dk w s'                                           true a = w' sigma           = av * (K / kk) * sig_scale
+//   bv  = av y + (w s' f'_u) cq_n,  cq_n = kk top / (K t_n) true b = (w' y + w y') sigma = bv * (K / kk) * sig_scale
+// with K = -2 scale, f'_u = df/ds (per unit of LUT coordinate), s' = sigma / sig_scale (the code u, the pixel x,
+// 1, or the explicit std), so the loop body has no multiply by scale, top, 1/max_code or std_value.
+// FOLD (integer codes only): the pixel value x is never formed; s and dk come straight from the code.
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FOLD, int PF = 2>
 __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
 {
     extern __shared__ __align__(16) char lds[];
-    constexpr bool kRanged = sizeof(T) != 4;
+    constexpr bool kInt = sizeof(T) != 4;
+    constexpr bool kRanged = kInt;
     constexpr bool kHasStd = STD != CT_STD_NONE;
+    constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
     constexpr int kEntry = lut_entry_bytes(INTERP);
+    static_assert(!FOLD || kInt, "FOLD is for integer codes");
     const int C = a.channels, L = a.n_points, B = a.batch;
     const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : C * L * kEntry;
-    float *inv_t = reinterpret_cast<float *>(lds + lut_bytes);
+    float *inv_t = reinterpret_cast<float *>(lds + lut_bytes);  // 1 / t_n
+    float *cq = inv_t + B;                                      // derivative scale per exposure
+    const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
+    const float kk = sqrtf(a.weight_scale * 1.4426950408889634f);
+    const float K = -2.0f * a.weight_scale;
 
     stage_lut<INTERP>(lds, a.lut, C, L);
-    for (int n = threadIdx.x; n < B; n += blockDim.x) inv_t[n] = (float)(1.0 / a.exposure[n]);
+    for (int n = threadIdx.x; n < B; n += blockDim.x) {
+        const float it = (float)(1.0 / a.exposure[n]);
+        inv_t[n] = it;
+        cq[n] = kGauss ? kk * top * it / K : top * it;
+    }
     __syncthreads();
 
     const uint32_t vec = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     if (vec * (uint32_t)V >= a.q_count) return;
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
-    const float top = (float)(L - 1);
 
     int row_off[V];  // byte offset of each element's LUT row inside the LDS table
 #pragma unroll
@@ -94,50 +112,140 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
 
     const T *src = static_cast<const T *>(a.stack) + q0;
     const float *ssrc = STD == CT_STD_EXPLICIT ? a.std_stack + q0 : nullptr;
+    const float dk_mul = FOLD ? kk * a.inv_max_code : kk, dk_add = -0.5f * kk;
 
-#pragma unroll 2
-    for (int n = 0; n < B; ++n) {
-        const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)n * a.image_stride);
-        Packet<float, V> sp;
+    // Software pipeline: PF packets (16-byte loads) are in flight per thread ahead of the one being reduced, and
+    // the V LDS gathers of a packet are issued together before any of them is consumed.
+    Packet<T, V> ring[PF];  // ring[0] is the packet being reduced; rotation is by register renaming after unroll
+    Packet<float, V> sring[STD == CT_STD_EXPLICIT ? PF : 1];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int nn = k < B ? k : B - 1;
+        ring[k] = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)nn * a.image_stride);
         if constexpr (STD == CT_STD_EXPLICIT)
-            sp = *reinterpret_cast<const Packet<float, V> *>(ssrc + (int64_t)n * a.image_stride);
+            sring[k] = *reinterpret_cast<const Packet<float, V> *>(ssrc + (int64_t)nn * a.image_stride);
+    }
+#pragma unroll PF
+    for (int n = 0; n < B; ++n) {
+        const int nn = n + PF < B ? n + PF : B - 1;  // tail re-loads the last exposure (cache hit, unused)
+        // The exposure offset is laundered through an empty asm each iteration: otherwise LLVM proves that the packet
+        // consumed in iteration n equals a fresh load of exposure n and re-loads it at the point of use, which
+        // deletes the prefetch (seen in the ISA: load, s_waitcnt vmcnt(0), use).
+        int64_t opaque_zero = 0;
+        asm volatile("" : "+s"(opaque_zero));
+        const int64_t eoff = (int64_t)nn * a.image_stride + opaque_zero;
+        const Packet<T, V> incoming = *reinterpret_cast<const Packet<T, V> *>(src + eoff);
+        Packet<float, V> sincoming;
+        if constexpr (STD == CT_STD_EXPLICIT) sincoming = *reinterpret_cast<const Packet<float, V> *>(ssrc + eoff);
+        const Packet<T, V> pk = ring[0];
+        const Packet<float, V> sp = sring[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PF; ++k) {
+            ring[k] = ring[k + 1];
+            if constexpr (STD == CT_STD_EXPLICIT) sring[k] = sring[k + 1];
+        }
+        ring[PF - 1] = incoming;
+        if constexpr (STD == CT_STD_EXPLICIT) sring[PF - 1] = sincoming;
         const float it = inv_t[n];
+        const float cqn = cq[n];
+        // ---- stage A: pixel / LUT coordinate, issue the LDS gathers ----
+        float pxv[V], frv[V], passv[V];
+        float ga[V], gb[V], gc[V], gd[V];  // LUT taps (LINEAR: a,b; CATMULL: a..d; LOOKUP: a)
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float x = to_pixel<T>(pk.v[e], a.norm);
-            float dfdx;
-            const float lin = icrf_sample<INTERP, false, kRanged>(x, lds + row_off[e], top, dfdx);
+            float px, s;
+            if constexpr (FOLD) {
+                px = (float)pk.v[e];
+                s = __builtin_fmaf(px, a.index.hi, px * a.index.lo);
+            } else {
+                px = to_pixel<T>(pk.v[e], a.norm);
+                s = px * top;
+            }
+            pxv[e] = px;
+            passv[e] = 1.0f;
+            frv[e] = 0.0f;
+            ga[e] = gb[e] = gc[e] = gd[e] = 0.0f;
+            if constexpr (INTERP == CT_INTERP_LOOKUP) {
+                float r = rintf(s);
+                if constexpr (!kRanged) r = fminf(fmaxf(r, 0.0f), top);
+                ga[e] = reinterpret_cast<const float *>(lds + row_off[e])[(int)r];
+            } else if constexpr (INTERP != CT_INTERP_NONE) {
+                if constexpr (!kRanged) {
+                    passv[e] = (s >= 0.0f && s <= top) ? 1.0f : 0.0f;
+                    s = fminf(fmaxf(s, 0.0f), top);
+                }
+                const int i0 = (int)s;  // s >= 0: truncation is floor
+                frv[e] = __builtin_amdgcn_fractf(s);
+                if constexpr (INTERP == CT_INTERP_LINEAR) {
+                    const float2 g = reinterpret_cast<const float2 *>(lds + row_off[e])[i0];
+                    ga[e] = g.x;
+                    gb[e] = g.y;
+                } else {
+                    const float4 g = reinterpret_cast<const float4 *>(lds + row_off[e])[i0];
+                    ga[e] = g.x;
+                    gb[e] = g.y;
+                    gc[e] = g.z;
+                    gd[e] = g.w;
+                }
+            }
+        }
+        // ---- stage B: f(x), weight, running sums ----
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float px = pxv[e];
+            float lin, dfds;
+            if constexpr (INTERP == CT_INTERP_NONE) {
+                lin = FOLD ? px * a.inv_max_code : px;
+                dfds = 1.0f;
+            } else if constexpr (INTERP == CT_INTERP_LOOKUP) {
+                lin = ga[e];
+                dfds = 0.0f;
+            } else if constexpr (INTERP == CT_INTERP_LINEAR) {
+                dfds = gb[e] - ga[e];
+                lin = __builtin_fmaf(dfds, frv[e], ga[e]);
+                if constexpr (!kRanged) dfds *= passv[e];
+            } else {
+                const float t = frv[e], t2 = t * t, t3 = t2 * t;
+                const float w0 = -0.5f * t3 + t2 - 0.5f * t, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
+                const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * t, w3 = 0.5f * t3 - 0.5f * t2;
+                lin = ((w0 * ga[e] + w1 * gb[e]) + w2 * gc[e]) + w3 * gd[e];
+                const float d0 = __builtin_fmaf(__builtin_fmaf(-1.5f, t, 2.0f), t, -0.5f);
+                const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
+                const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
+                dfds = __builtin_fmaf(d0, ga[e] - gb[e], __builtin_fmaf(d2, gc[e] - gb[e], d3 * (gd[e] - gb[e])));
+                if constexpr (!kRanged) dfds *= passv[e];
+            }
             const float y = lin * it;
-            float w, wp;
-            if constexpr (WEIGHT == CT_WEIGHT_GAUSS) {
-                const float d = x - 0.5f;
-                w = __builtin_amdgcn_exp2f((d * d) * a.neg_scale_log2e);
-                wp = (d * w) * a.neg_two_scale;
+            float sg = 1.0f;
+            if constexpr (STD == CT_STD_EXPLICIT) sg = sp.v[e];
+            if constexpr (STD == CT_STD_MULTIPLIER) sg = px;
+            if constexpr (kGauss) {
+                const float dk = __builtin_fmaf(px, dk_mul, dk_add);
+                const float w = __builtin_amdgcn_exp2f(-dk * dk);
                 W[e] += w;
                 Swy[e] = __builtin_fmaf(w, y, Swy[e]);
-            } else {
-                w = 1.0f;
-                wp = 0.0f;
-                Swy[e] += y;
-            }
-            if constexpr (kHasStd) {
-                float sigma;
-                if constexpr (STD == CT_STD_EXPLICIT)
-                    sigma = sp.v[e];
-                else if constexpr (STD == CT_STD_MULTIPLIER)
-                    sigma = x;  // std_value applied once at the end
-                else
-                    sigma = 1.0f;
-                const float yp = dfdx * it;
-                if constexpr (WEIGHT == CT_WEIGHT_GAUSS) {
-                    const float av = wp * sigma;
-                    const float bv = __builtin_fmaf(wp, y, w * yp) * sigma;
+                if constexpr (kHasStd) {
+                    const float wu = (STD == CT_STD_CONSTANT) ? w : w * sg;
+                    const float av = dk * wu;
+                    float bv;
+                    if constexpr (INTERP == CT_INTERP_LOOKUP)
+                        bv = av * y;
+                    else if constexpr (INTERP == CT_INTERP_NONE)
+                        bv = __builtin_fmaf(av, y, wu * cqn);
+                    else
+                        bv = __builtin_fmaf(av, y, (wu * dfds) * cqn);
+                    // float64 FMAs: the quadratic form below cancels by 1e2..1e4 (LOOKUP: b = a y exactly);
+                    // float32 block sums were measured 7 % faster and 1.3e-4 off on such cases -- not worth it.
                     const double ad = (double)av, bd = (double)bv;
                     Saa[e] = __builtin_fma(ad, ad, Saa[e]);
                     Sab[e] = __builtin_fma(ad, bd, Sab[e]);
                     Sbb[e] = __builtin_fma(bd, bd, Sbb[e]);
-                } else {
-                    const double bd = (double)(yp * sigma);
+                }
+            } else {
+                Swy[e] += y;
+                if constexpr (kHasStd) {
+                    const float bv = (INTERP == CT_INTERP_NONE ? sg : dfds * sg) * cqn;
+                    const double bd = (double)bv;
                     Sbb[e] = __builtin_fma(bd, bd, Sbb[e]);
                 }
             }
@@ -147,15 +255,19 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     const bool first = a.flags & CT_MERGE_FIRST_BATCH;
     const bool finalize = a.flags & CT_MERGE_FINALIZE;
     const bool keep_state = a.mean_state != nullptr;
-    const double sv2 = (STD == CT_STD_CONSTANT || STD == CT_STD_MULTIPLIER) ? (double)a.std_value * (double)a.std_value
-                                                                           : 1.0;
+    // scale of the folded second moments back to true units
+    double fs = 1.0;
+    if constexpr (kGauss) fs = (double)K / (double)kk;
+    if constexpr (STD == CT_STD_CONSTANT) fs *= (double)a.std_value;
+    if constexpr (STD == CT_STD_MULTIPLIER) fs *= (double)a.std_value * (FOLD ? (double)a.inv_max_code : 1.0);
+    const double sv2 = fs * fs;
     double mean_o[V];
     float std_o[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         const uint32_t q = q0 + e;
         float Wb = W[e];
-        if constexpr (WEIGHT != CT_WEIGHT_GAUSS) Wb = (float)B;
+        if constexpr (!kGauss) Wb = (float)B;
         const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
         const double D = (double)Df;
         const double mb = (double)Swy[e] / D;
@@ -201,57 +313,66 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
 }
 
 template <typename T, int V, int INTERP, int WEIGHT, int STD>
-static int launch_one(const MergeArgs &a, hipStream_t stream)
+static int launch_one(const MergeArgs &a, hipStream_t stream, bool fold)
 {
     if (a.q_count == 0) return CT_OK;
     const uint32_t vecs = a.q_count / V;
     const uint32_t grid = (vecs + kBlock - 1) / kBlock;
     const size_t lds = (INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP)) +
-                       sizeof(float) * (size_t)a.batch;
+                       2 * sizeof(float) * (size_t)a.batch;
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
-    hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD>), dim3(grid), dim3(kBlock), lds, stream, a);
+    if constexpr (sizeof(T) != 4) {
+        if (fold)
+            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, true>), dim3(grid), dim3(kBlock), lds, stream, a);
+        else
+            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+    }
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
 template <typename T, int V, int INTERP, int WEIGHT>
-static int dispatch_std(const MergeArgs &a, int std_mode, hipStream_t s)
+static int dispatch_std(const MergeArgs &a, int std_mode, hipStream_t s, bool fold)
 {
     switch (std_mode) {
-        case CT_STD_NONE: return launch_one<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, s);
-        case CT_STD_CONSTANT: return launch_one<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, s);
-        case CT_STD_MULTIPLIER: return launch_one<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER>(a, s);
-        case CT_STD_EXPLICIT: return launch_one<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT>(a, s);
+        case CT_STD_NONE: return launch_one<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, s, fold);
+        case CT_STD_CONSTANT: return launch_one<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, s, fold);
+        case CT_STD_MULTIPLIER: return launch_one<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER>(a, s, fold);
+        case CT_STD_EXPLICIT: return launch_one<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT>(a, s, fold);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
 
 template <typename T, int V, int INTERP>
-static int dispatch_weight(const MergeArgs &a, int weight_mode, int std_mode, hipStream_t s)
+static int dispatch_weight(const MergeArgs &a, int weight_mode, int std_mode, hipStream_t s, bool fold)
 {
-    return weight_mode == CT_WEIGHT_GAUSS ? dispatch_std<T, V, INTERP, CT_WEIGHT_GAUSS>(a, std_mode, s)
-                                          : dispatch_std<T, V, INTERP, CT_WEIGHT_NONE>(a, std_mode, s);
+    return weight_mode == CT_WEIGHT_GAUSS ? dispatch_std<T, V, INTERP, CT_WEIGHT_GAUSS>(a, std_mode, s, fold)
+                                          : dispatch_std<T, V, INTERP, CT_WEIGHT_NONE>(a, std_mode, s, fold);
 }
 
 template <typename T, int V>
-static int dispatch_interp(const MergeArgs &a, int interp, int weight_mode, int std_mode, hipStream_t s)
+static int dispatch_interp(const MergeArgs &a, int interp, int weight_mode, int std_mode, hipStream_t s, bool fold)
 {
     switch (interp) {
-        case CT_INTERP_LOOKUP: return dispatch_weight<T, V, CT_INTERP_LOOKUP>(a, weight_mode, std_mode, s);
-        case CT_INTERP_LINEAR: return dispatch_weight<T, V, CT_INTERP_LINEAR>(a, weight_mode, std_mode, s);
-        case CT_INTERP_CATMULL: return dispatch_weight<T, V, CT_INTERP_CATMULL>(a, weight_mode, std_mode, s);
-        case CT_INTERP_NONE: return dispatch_weight<T, V, CT_INTERP_NONE>(a, weight_mode, std_mode, s);
+        case CT_INTERP_LOOKUP: return dispatch_weight<T, V, CT_INTERP_LOOKUP>(a, weight_mode, std_mode, s, fold);
+        case CT_INTERP_LINEAR: return dispatch_weight<T, V, CT_INTERP_LINEAR>(a, weight_mode, std_mode, s, fold);
+        case CT_INTERP_CATMULL: return dispatch_weight<T, V, CT_INTERP_CATMULL>(a, weight_mode, std_mode, s, fold);
+        case CT_INTERP_NONE: return dispatch_weight<T, V, CT_INTERP_NONE>(a, weight_mode, std_mode, s, fold);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
 
-// Vector width per element type: 16-byte packets for the integer codes, 16 bytes for float32.
+// Elements per thread.  Measured on MI355X (tools/merge_bench.hip, C2 shape, Gaussian + MULTIPLIER std):
+// uint16 V=4 (8-byte packets) 1.18-1.22 ms vs V=8 (16-byte) 1.22-1.26 ms: the kernel is VALU-bound with the
+// uncertainty on, so the smaller register footprint (more resident waves) wins over the wider load.
 template <typename T>
 struct VecWidth {
-    static constexpr int value = 16 / sizeof(T) > 8 ? 8 : 16 / sizeof(T);
+    static constexpr int value = sizeof(T) == 1 ? 8 : 4;
 };
 
 template <typename T>
-static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s)
+static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s, bool fold)
 {
     constexpr int V = VecWidth<T>::value;
     // The packet path needs every packet naturally aligned in every exposure: base pointers and the image
@@ -266,13 +387,13 @@ static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int
     if (q_vec) {
         a.q_begin = 0;
         a.q_count = q_vec;
-        rc = dispatch_interp<T, V>(a, interp, weight_mode, std_mode, s);
+        rc = dispatch_interp<T, V>(a, interp, weight_mode, std_mode, s, fold);
         if (rc != CT_OK) return rc;
     }
     if (q_vec < Q) {
         a.q_begin = q_vec;
         a.q_count = Q - q_vec;
-        rc = dispatch_interp<T, 1>(a, interp, weight_mode, std_mode, s);
+        rc = dispatch_interp<T, 1>(a, interp, weight_mode, std_mode, s, fold);
     }
     return rc;
 }
@@ -281,6 +402,7 @@ static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int
 
 // Host check that fma(u, hi, u*lo) == u / max_code for every code (see NormConst in ct_device.hpp).
 extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
+extern "C" int ct_index_constants(float max_code, int n_points, float *hi, float *lo);
 
 extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int32_t batch,
                                   const ct_geometry *geom, const float *std_dev, int32_t std_mode, float std_value,
@@ -330,19 +452,21 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
     a.channels = geom->channels;
     a.n_points = interp == CT_INTERP_NONE ? 2 : icrf->n_points;
     a.std_value = std_value;
-    const float scale = 30.0f;  // gaussian_value_weights default, hdr_merge.py:95
-    a.neg_scale_log2e = -scale * 1.4426950408889634f;
-    a.neg_two_scale = -2.0f * scale;
+    a.weight_scale = 30.0f;  // gaussian_value_weights default scale, hdr_merge.py:95
+    a.inv_max_code = 1.0f;
     a.flags = flags;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
         case CT_DTYPE_U8:
+        case CT_DTYPE_U16: {
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
-            return merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s);
-        case CT_DTYPE_U16:
-            if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
-            return merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s);
-        case CT_DTYPE_F32: return merge_typed<float>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s);
+            // FOLD needs the LUT index formed from the code to equal the reference's float32 index for every code
+            const bool fold = ct_index_constants(max_code, a.n_points, &a.index.hi, &a.index.lo) == CT_OK;
+            a.inv_max_code = (float)(1.0 / (double)max_code);
+            return dtype == CT_DTYPE_U8 ? merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold)
+                                        : merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold);
+        }
+        case CT_DTYPE_F32: return merge_typed<float>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, false);
     }
     return CT_ERR_UNSUPPORTED;
 }

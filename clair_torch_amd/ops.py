@@ -205,3 +205,102 @@ def icrf_backward(x: torch.Tensor, grad_out: torch.Tensor, lut: torch.Tensor, in
     nv.check(rc, "ct_linearize_bwd")
     del lut_keep
     return gx, gl
+
+
+# ---- exposure-pair linearity residual (training / measure_linearity) -----------------------------------------
+def _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value, weight_scale=10.0):
+    return nv.PairParams(lower=float(lower), upper=float(upper), weight_scale=float(weight_scale),
+                         use_relative=int(bool(use_relative)), use_uncertainty_weighting=int(bool(use_unc_weight)),
+                         std_mode=_STD[std_mode], std_value=float(std_value))
+
+
+class PairList:
+    """Exposure pairs on the device: (i, j, ratio) in the reference's triu order plus the per-sample partner
+    lists (CSR) the backward kernel walks.  Built from get_valid_exposure_pairs' outputs (tiny, host-side)."""
+
+    def __init__(self, i_idx: torch.Tensor, j_idx: torch.Tensor, ratio: torch.Tensor, n_images: int, device):
+        i_cpu, j_cpu = i_idx.to("cpu", torch.int64), j_idx.to("cpu", torch.int64)
+        self.n_pairs, self.n_images = int(i_cpu.numel()), int(n_images)
+        self.i = i_cpu.to(torch.int32).to(device)
+        self.j = j_cpu.to(torch.int32).to(device)
+        self.ratio = ratio.to("cpu", torch.float64).to(device)
+        offsets, samples, codes = [0], [], []
+        il, jl = i_cpu.tolist(), j_cpu.tolist()
+        for n in range(n_images):
+            for p, (a, b) in enumerate(zip(il, jl)):
+                if a == n:
+                    samples.append(b)
+                    codes.append(p)
+                elif b == n:
+                    samples.append(a)
+                    codes.append(~p)
+            offsets.append(len(samples))
+        self.part_off = torch.tensor(offsets, dtype=torch.int32, device=device)
+        self.part_sample = torch.tensor(samples or [0], dtype=torch.int32, device=device)
+        self.part_pair = torch.tensor(codes or [0], dtype=torch.int32, device=device)
+
+
+def pair_residual_sums(stack: torch.Tensor, pairs: PairList, *, lut: Optional[torch.Tensor], interp: Optional[str],
+                       lower: float, upper: float, use_relative: bool, use_unc_weight: bool,
+                       std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
+                       max_code: Optional[float] = None, level: int = 1, tile: Optional[TileGeometry] = None,
+                       center: Optional[torch.Tensor] = None):
+    """ct_pair_residual_fwd -> (P, C, 5) float64 sums [sum w m, sum v w m, sum (v-center)^2 w m, sum err m, sum m]."""
+    _check_stack(stack)
+    n, c, _, _ = stack.shape
+    dev = stack.device
+    if n != pairs.n_images:
+        raise ValueError(f"pair list was built for {pairs.n_images} images, stack has {n}")
+    if std is not None:
+        std_mode = "explicit"
+        _require_device(std, "std")
+        if std.shape != stack.shape:
+            raise ValueError("std shape != stack shape")
+        std = std.to(torch.float32).contiguous()
+        stack = stack.contiguous()
+    if stack.dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
+    icrf, lut_keep = _icrf_struct(lut, interp, c)
+    geom = _geometry(stack, tile)
+    prm = _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value)
+    sums = torch.zeros((pairs.n_pairs, c, 5), dtype=torch.float64, device=dev)
+    if center is not None:
+        center = center.to(device=dev, dtype=torch.float64).contiguous()
+        if center.shape != (pairs.n_pairs, c):
+            raise ValueError(f"center must be (P={pairs.n_pairs}, C={c})")
+    if pairs.n_pairs:
+        with torch.cuda.device(dev):
+            rc = nv.load().ct_pair_residual_fwd(_ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), n,
+                                                ctypes.byref(geom), _ptr(std), ctypes.byref(icrf), _ptr(pairs.i),
+                                                _ptr(pairs.j), _ptr(pairs.ratio), pairs.n_pairs, ctypes.byref(prm),
+                                                int(level), _ptr(center), _ptr(sums), _stream(dev))
+        nv.check(rc, "ct_pair_residual_fwd")
+    del lut_keep
+    return sums
+
+
+def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Tensor, *, lut: torch.Tensor, interp: str,
+                           lower: float, upper: float, use_relative: bool, max_code: Optional[float] = None,
+                           tile: Optional[TileGeometry] = None):
+    """ct_pair_residual_bwd -> (C, L) float64 gradient of sum_pc coef_pc * (sum v w m)_pc with respect to the LUT."""
+    _check_stack(stack)
+    n, c, _, _ = stack.shape
+    dev = stack.device
+    if stack.dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
+    icrf, lut_keep = _icrf_struct(lut, interp, c)
+    geom = _geometry(stack, tile)
+    prm = _pair_params(lower, upper, use_relative, False, "none", 0.0)
+    coef = coef.to(device=dev, dtype=torch.float64).contiguous()
+    if coef.shape != (pairs.n_pairs, c):
+        raise ValueError(f"coef must be (P={pairs.n_pairs}, C={c}), got {tuple(coef.shape)}")
+    grad = torch.zeros((c, lut.shape[1]), dtype=torch.float64, device=dev)
+    if pairs.n_pairs:
+        with torch.cuda.device(dev):
+            rc = nv.load().ct_pair_residual_bwd(_ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), n,
+                                                ctypes.byref(geom), ctypes.byref(icrf), _ptr(pairs.ratio), pairs.n_pairs,
+                                                _ptr(pairs.part_off), _ptr(pairs.part_sample), _ptr(pairs.part_pair),
+                                                ctypes.byref(prm), _ptr(coef), _ptr(grad), _stream(dev))
+        nv.check(rc, "ct_pair_residual_bwd")
+    del lut_keep
+    return grad

@@ -128,6 +128,54 @@ int ct_linearize_fwd(const float *x_dev, int64_t n_images, const ct_geometry *ge
 int ct_linearize_bwd(const float *x_dev, const float *grad_out_dev, int64_t n_images, const ct_geometry *geom,
                      const ct_icrf *icrf, float *grad_x_dev, float *lut_grad_dev, void *stream);
 
+/* Parameters of the exposure-pair linearity residual (train_icrf / measure_linearity). */
+typedef struct ct_pair_params {
+    float lower, upper;                 /* inclusive validity range of the raw pixel value (general_functions.py:302) */
+    float weight_scale;                 /* Gaussian pair-weight scale, 10 in the reference (losses.py:212) */
+    int32_t use_relative;               /* use_relative_linearity_loss */
+    int32_t use_uncertainty_weighting;  /* add 1 / (err + 1e-6) to the weights (losses.py:96) */
+    int32_t std_mode;                   /* CT_STD_*: source of sigma for the linearized std |f'(x) sigma| */
+    float std_value;
+} ct_pair_params;
+
+/*
+ * ct_pair_residual_fwd -- spatial sums of the per-pixel linearity residual for P exposure pairs; replaces
+ * get_pairwise_valid_pixel_mask + combined_gaussian_pair_weights + model forward + pixelwise_linearity_loss +
+ * compute_spatial_linearity_loss of one train_icrf step (clair_torch/training/icrf_training.py:105-133) or of
+ * measure_linearity (clair_torch/inference/measure_linearity.py:44-72).
+ *   stack_dev (N, C, H_tile, W); i_idx_dev / j_idx_dev (P) int32, ratio_dev (P) float64 = t_i / t_j
+ *   (get_valid_exposure_pairs, common/general_functions.py:242-272)
+ *   level 0: sums 0..1 only (training), level 1: all five sums
+ *   center_dev (P, C) float64 or NULL: value subtracted from v inside sum [2].  The weighted std needs
+ *     sum (v - mean)^2 w m (general_functions.py:163-165); expanding it from raw moments cancels by (mean/std)^2, so
+ *     callers run level 1 twice: once for the means, once with center = mean.
+ *   sums_dev (P, C, 5) float64, ACCUMULATED (+=, caller zeroes; tiles / ranks add up):
+ *     [0] sum w m   [1] sum v w m   [2] sum (v - center)^2 w m   [3] sum err m   [4] sum m
+ *   with v the (relative) absolute residual, w the weight, m the validity mask, err the residual's uncertainty.
+ *   spatial mean = [1] / max([0], 1e-8), etc. (general_functions.py:149-170).
+ */
+int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
+                         const ct_geometry *geom, const float *std_dev, const ct_icrf *icrf, const int32_t *i_idx_dev,
+                         const int32_t *j_idx_dev, const double *ratio_dev, int32_t n_pairs,
+                         const ct_pair_params *params, int32_t level, const double *center_dev, double *sums_dev,
+                         void *stream);
+
+/*
+ * ct_pair_residual_bwd -- gradient of the training loss's linearity term with respect to the (C, L) LUT
+ * (what loss[c].backward() deposits in the model parameters, icrf_training.py:148-149, for that term).
+ *   coef_dev (P, C) float64 = dL/d(spatial mean_pc) / max(sums[p][c][0], 1e-8)
+ *   partner lists (CSR over samples): for sample n, entries partner_offsets[n] .. partner_offsets[n+1]-1 give the
+ *   other sample of every pair containing n (partner_sample_dev) and the pair id (partner_pair_dev: p when n is
+ *   the pair's first image i, ~p when it is the second image j)
+ *   lut_grad_dev (C, L) float64, ACCUMULATED (+=)
+ * Unsupported (CT_ERR_UNSUPPORTED): use_uncertainty_weighting with stds (the weights then depend on the LUT).
+ */
+int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
+                         const ct_geometry *geom, const ct_icrf *icrf, const double *ratio_dev, int32_t n_pairs,
+                         const int32_t *partner_offsets_dev, const int32_t *partner_sample_dev,
+                         const int32_t *partner_pair_dev, const ct_pair_params *params, const double *coef_dev,
+                         double *lut_grad_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,143 @@
+"""GPU parity tests of ICRF linearization: ct_linearize_std / ct_linearize_fwd / ct_linearize_bwd."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from _util import assert_parity, golden, std_for
+
+pytestmark = pytest.mark.gpu
+MODES = ("lookup", "linear", "catmull")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clair_torch_amd import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+@pytest.mark.parametrize("mode", MODES)
+def test_model_forward_bit_exact(dev, case, mode):
+    """ICRFModelDirect.forward equals the reference bit for bit in all three interpolation modes, incl. exact knots,
+    0, 1 and out-of-range values, on shapes where H*W is not a multiple of C (row quirk)."""
+    from clair_torch_amd.common.enums import InterpMode
+    from clair_torch_amd.models import ICRFModelDirect
+    g = golden("model_forward")
+    model = ICRFModelDirect(icrf=torch.from_numpy(g["fwd_lut"]), interpolation_mode=InterpMode[mode.upper()]).to(dev)
+    out = model(torch.from_numpy(g[f"fwd_{case}_x"]).to(dev))
+    assert np.array_equal(out.cpu().numpy(), g[f"fwd_{case}_{mode}"])
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_every_code_bit_exact(dev, bits):
+    """All 256 / 65536 integer codes through in-kernel normalisation + LUT: value bit-exact (uint LUT indexing)."""
+    from clair_torch_amd import ops
+    g = golden("model_forward")
+    lut = torch.from_numpy(g["fwd_lut"]).to(dev)
+    u = torch.arange(2 ** bits, dtype=torch.int32).to(torch.uint8 if bits == 8 else torch.uint16)
+    frames = u.view(1, 1, 1, -1).repeat(1, 3, 1, 1).contiguous().to(dev)
+    for mode in MODES:
+        lin, _ = ops.linearize_frames(frames, lut, mode, want_std=False)
+        assert np.array_equal(lin.cpu().numpy(), g[f"codes{bits}_{mode}"]), mode
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sname", ["none", "multiplier", "explicit"])
+def test_linearize_generator_vs_golden(dev, mode, sname):
+    """linearize_dataset_generator: value bit-exact; std bit-exact for LINEAR (CATMULL: the reference's own
+    float32 autograd noise bounds the comparison, see test_oracle_golden)."""
+    from clair_torch_amd.common.enums import InterpMode, MissingStdMode
+    from clair_torch_amd.common.transforms import CastTo, Normalize
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.inference import linearize_dataset_generator
+    from clair_torch_amd.models import ICRFModelDirect
+    from oracle import ct_oracle as oc
+    g = golden("linearize")
+    codes = torch.from_numpy(g["lin_codes"])
+    model = ICRFModelDirect(icrf=torch.from_numpy(g["lin_lut"]), interpolation_mode=InterpMode[mode.upper()]).to(dev)
+    if sname == "explicit":
+        x = torch.from_numpy(oc.normalize_codes(g["lin_codes"]))
+        ds = StackDataset(x, [0.01, 0.02, 0.04], stds=torch.from_numpy(g["lin_explicit_std"]))
+        tf = None
+    elif sname == "multiplier":
+        ds = StackDataset(codes, [0.01, 0.02, 0.04], missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05,
+                          materialize_std=False)
+        tf = [CastTo("float32"), Normalize(max_val=65535, min_val=0)]
+    else:
+        ds = StackDataset(codes, [0.01, 0.02, 0.04])
+        tf = [CastTo("float32"), Normalize(max_val=65535, min_val=0)]
+    loader = DataLoader(ds, batch_size=1, shuffle=False, collate_fn=custom_collate)
+    if mode == "lookup" and sname != "none":
+        with pytest.raises(RuntimeError, match="does not require grad"):
+            next(iter(linearize_dataset_generator(loader, "cuda", model, gpu_transforms=tf)))
+        return
+    outs = list(linearize_dataset_generator(loader, "cuda", model, gpu_transforms=tf))
+    assert len(outs) == 3
+    for f, (lin, sd, meta) in enumerate(outs):
+        assert lin.device.type == "cpu" and sd.device.type == "cpu" and lin.dtype == torch.float32
+        assert np.array_equal(lin.numpy(), g[f"lin_{mode}_{sname}_val"][f])
+        if mode == "catmull":
+            assert_parity(sd.numpy(), g[f"lin_{mode}_{sname}_std"][f], norm_tol=5e-5, elem_tol=5e-4, what="std")
+        else:
+            assert np.array_equal(sd.numpy(), g[f"lin_{mode}_{sname}_std"][f])
+        assert float(meta["exposure_time"]) == [0.01, 0.02, 0.04][f]
+
+
+def test_linearize_batch_size_must_be_one(dev):
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.inference import linearize_dataset_generator
+    from clair_torch_amd.models import ICRFModelDirect
+    ds = StackDataset(torch.rand(4, 3, 8, 8), [1, 2, 3, 4])
+    loader = DataLoader(ds, batch_size=2, collate_fn=custom_collate)
+    with pytest.raises(ValueError, match="batch_size of 1"):
+        next(iter(linearize_dataset_generator(loader, "cuda", ICRFModelDirect().to(dev))))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_backward_matches_eager_autograd(dev, mode):
+    """Image gradient and (C,L) LUT gradient of the HIP forward/backward pair vs the eager-PyTorch restatement."""
+    from clair_torch_amd.common.enums import InterpMode
+    from clair_torch_amd.models import ICRFModelDirect
+    from oracle import eager_torch as oe
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand((3, 3, 17, 13), generator=gen)
+    x.view(-1)[:4] = torch.tensor([0.0, 1.0, 100 / 255, 1.25])
+    go = torch.randn((3, 3, 17, 13), generator=gen)
+    lut0 = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.5, 2.0, 2.5)])
+    # oracle
+    xo, lo = x.clone().requires_grad_(True), lut0.clone().requires_grad_(True)
+    out_o = oe.icrf_forward(xo, lo, mode)
+    grads = torch.autograd.grad(out_o, [lo] + ([xo] if mode != "lookup" else []), go)
+    # HIP
+    model = ICRFModelDirect(icrf=lut0.clone(), interpolation_mode=InterpMode[mode.upper()]).to(dev)
+    with torch.no_grad():
+        for c in range(3):
+            model.direct_params[c].copy_(lut0[c])
+    model.update_icrf()
+    xd = x.to(dev).requires_grad_(True)
+    out = model(xd)
+    assert np.array_equal(out.detach().cpu().numpy(), out_o.detach().numpy())
+    out.backward(go.to(dev))
+    lut_grad = torch.stack([p.grad for p in model.direct_params]).cpu()
+    assert_parity(lut_grad.numpy(), grads[0].numpy(), rtol=1e-5, norm_tol=1e-6, what="lut grad")
+    if mode != "lookup":
+        tol = dict(rtol=1e-5, norm_tol=1e-6) if mode == "linear" else dict(rtol=1e-4, norm_tol=2e-5)
+        assert_parity(xd.grad.cpu().numpy(), grads[1].numpy(), what="image grad", **tol)
+
+
+def test_linearize_streamed_frames_vs_oracle(dev):
+    """Config C4 shape (1920x1080x3 frames, uint8 and uint16, many frames per launch) against the C oracle."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(5)
+    lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(p) for p in (2.2, 2.4, 2.6)])
+    for dt, hi in ((np.uint8, 256), (np.uint16, 65536)):
+        codes = rng.integers(0, hi, size=(4, 3, 1080, 1920)).astype(dt)
+        lin, sd = ops.linearize_frames(torch.from_numpy(codes).to(dev), torch.from_numpy(lut).to(dev), "linear",
+                                       std_mode="multiplier", std_value=0.05)
+        x = oc.normalize_codes(codes)
+        lin_o, sd_o = oc.linearize_std(x, x * np.float32(0.05), lut, "linear")
+        assert np.array_equal(lin.cpu().numpy(), lin_o) and np.array_equal(sd.cpu().numpy(), sd_o)

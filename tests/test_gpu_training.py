@@ -1,0 +1,204 @@
+"""GPU parity tests of the exposure-pair linearity kernels (ct_pair_residual_fwd / _bwd), measure_linearity and
+train_icrf against vectors recorded from the reference (tests/golden/training.npz) and the eager oracle."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from _util import assert_parity, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clair_torch_amd import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def _inputs(g, dev, as_codes=True):
+    from oracle import ct_oracle as oc
+    codes = g["train_codes"]
+    x = oc.normalize_codes(codes)
+    stack = torch.from_numpy(codes if as_codes else x).to(dev)
+    return stack, x
+
+
+def _pairs(g, dev, thr):
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    t = torch.from_numpy(g["train_exposures"])
+    i, j, r = get_valid_exposure_pairs(t, thr)
+    return ops.PairList(i, j, r, t.numel(), dev), (i, j, r)
+
+
+def test_exposure_pairs_match_reference(dev):
+    g = golden("training")
+    _, (i, j, r) = _pairs(g, dev, 0.25)
+    assert np.array_equal(i.numpy(), g["train_i_idx"]) and np.array_equal(j.numpy(), g["train_j_idx"])
+    assert np.array_equal(r.numpy(), g["train_ratio"])
+
+
+@pytest.mark.parametrize("as_codes", [True, False])
+@pytest.mark.parametrize("sname", ["none", "multiplier"])
+@pytest.mark.parametrize("mode", ["linear", "catmull"])
+def test_pair_sums_vs_golden(dev, as_codes, sname, mode):
+    """Spatial mean / std / error and the mask popcount of every pair and channel, all four loss variants."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.training import spatial_mean, spatial_statistics
+    g = golden("training")
+    stack, _ = _inputs(g, dev, as_codes)
+    pairs, _ = _pairs(g, dev, 0.25)
+    lut = torch.from_numpy(g["train_lut0"]).to(dev)
+    for rel in (True, False):
+        for unc in (True, False):
+            kw = dict(std_mode="multiplier", std_value=0.05) if sname == "multiplier" else {}
+            kw.update(lut=lut, interp=mode, lower=1 / 255, upper=254 / 255, use_relative=rel, use_unc_weight=unc, level=1)
+            sums = ops.pair_residual_sums(stack, pairs, **kw)
+            assert np.array_equal(sums[..., 4].cpu().numpy(), g[f"train_{sname}_mask_popcount"].astype(np.float64))
+            centered = ops.pair_residual_sums(stack, pairs, center=spatial_mean(sums), **kw)
+            mean, sd, err = spatial_statistics(sums, centered, sname != "none")
+            key = f"train_{sname}_{mode}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+            assert_parity(mean.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " mean")
+            assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=2e-5, norm_tol=5e-6, what=key + " std")
+            if sname != "none":
+                assert_parity(err.cpu().numpy(), g[key + "_spatial_err"], rtol=1e-5, norm_tol=2e-6, what=key + " err")
+
+
+@pytest.mark.parametrize("mode", ["linear", "catmull"])
+@pytest.mark.parametrize("rel", [True, False])
+def test_linearity_loss_and_lut_gradient(dev, mode, rel):
+    """Per-channel linearity loss and its (C,L) LUT gradient: what loss[c].backward() deposits for that term."""
+    from clair_torch_amd.training import linearity_loss
+    g = golden("training")
+    stack, _ = _inputs(g, dev)
+    pairs, _ = _pairs(g, dev, 0.25)
+    lut = torch.from_numpy(g["train_lut0"]).to(dev).requires_grad_(True)
+    lin, spatial = linearity_loss(lut, stack, pairs, interp=mode, lower=1 / 255, upper=254 / 255, use_relative=rel,
+                                  use_unc_weight=False)
+    key = f"train_none_{mode}_{'rel' if rel else 'abs'}_nounc"
+    assert lin.dtype == torch.float64
+    assert_parity(lin.detach().cpu().numpy(), g[key + "_linloss"], rtol=1e-5, norm_tol=2e-6, what=key + " linloss")
+    assert_parity(spatial.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " spatial")
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert grad.shape == lut.shape and grad.dtype == torch.float32
+    # the reference accumulates this gradient in float32 through index_put; element-wise it is only good to ~1e-4
+    assert_parity(grad.cpu().numpy(), g[key + "_lingrad"], norm_tol=2e-5, elem_tol=2e-4, what=key + " lingrad")
+    # with uncertainty images but without uncertainty weighting the loss is unchanged (losses.py:93-100)
+    lin2, _ = linearity_loss(lut, stack, pairs, interp=mode, lower=1 / 255, upper=254 / 255, use_relative=rel,
+                             use_unc_weight=False, std_mode="multiplier", std_value=0.05)
+    assert torch.equal(lin2.detach(), lin.detach())
+
+
+def test_lut_gradient_vs_eager_oracle_large(dev):
+    """A bigger, ragged case (plane not a multiple of the tile, 9 exposures, 64-sample LUT) against the eager
+    float64-residual oracle; also checks the tile decomposition: two row bands sum to the whole."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.training import linearity_loss
+    from oracle import eager_torch as oe
+    gen = torch.Generator().manual_seed(21)
+    n, c, h, w = 9, 3, 61, 47
+    t = torch.tensor([0.001 * 2.0 ** (k / 2.0) for k in range(n)], dtype=torch.float64)
+    e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / float(torch.sqrt(t[0] * t[-1])))
+    x = ((e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0, 1) ** (1 / 2.2)).float()
+    x = (x + 0.01 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    lut0 = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.9, 2.2, 2.5)])
+    lo = lut0.clone().requires_grad_(True)
+    _, lin_o, sp_o = oe.training_loss(x, None, t, lo, "linear", 0.25, 1 / 255, 254 / 255, True, False)
+    grad_o = torch.autograd.grad(lin_o.sum(), lo)[0]
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    dev_x = x.to(dev)
+    pairs = ops.PairList(i, j, r, n, dev)
+    lut = lut0.to(dev).requires_grad_(True)
+    lin, sp = linearity_loss(lut, dev_x, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
+                             use_unc_weight=False)
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="spatial")
+    assert_parity(lin.detach().cpu().numpy(), lin_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="lin loss")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="lut grad")
+    # tiles: sums are additive over row bands when the global geometry is passed
+    kw = dict(lut=lut.detach(), interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False)
+    whole = ops.pair_residual_sums(dev_x, pairs, level=1, **kw)
+    parts = [ops.pair_residual_sums(dev_x[:, :, r0:r1].contiguous(), pairs, level=1,
+                                    tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw)
+             for r0, r1 in ((0, 20), (20, 61))]
+    assert_parity((parts[0] + parts[1]).cpu().numpy(), whole.cpu().numpy(), rtol=1e-6, norm_tol=1e-6, what="tiles")
+
+
+@pytest.mark.parametrize("sname", ["none", "multiplier"])
+@pytest.mark.parametrize("mname", ["nomodel", "linear"])
+def test_measure_linearity_api(dev, sname, mname):
+    from clair_torch_amd.common.enums import InterpMode, MissingStdMode
+    from clair_torch_amd.common.transforms import CastTo, Normalize
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.inference import measure_linearity
+    from clair_torch_amd.models import ICRFModelDirect
+    g = golden("training")
+    codes = torch.from_numpy(g["train_codes"])
+    mode = MissingStdMode.MULTIPLIER if sname == "multiplier" else MissingStdMode.NONE
+    ds = StackDataset(codes, g["train_exposures"].tolist(), missing_std_mode=mode, missing_std_value=0.05,
+                      materialize_std=False)
+    loader = DataLoader(ds, batch_size=codes.shape[0], shuffle=False, collate_fn=custom_collate)
+    model = None if mname == "nomodel" else ICRFModelDirect(icrf=torch.from_numpy(g["train_lut0"]),
+                                                            interpolation_mode=InterpMode.LINEAR).to(dev)
+    for rel in (True, False):
+        for unc in (True, False):
+            ratio, mean, sd, err = measure_linearity(loader, "cuda", unc, rel, model,
+                                                     gpu_transforms=[CastTo("float32"), Normalize(255, 0)])
+            key = f"meas_{sname}_{mname}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+            assert np.array_equal(ratio.cpu().numpy(), g[key + "_ratio"])
+            assert_parity(mean.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key)
+            assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=2e-5, norm_tol=5e-6, what=key + " std")
+            if sname == "none":
+                assert err is None
+            else:
+                assert_parity(err.cpu().numpy(), g[key + "_spatial_err"], rtol=1e-5, norm_tol=2e-6, what=key + " err")
+
+
+@pytest.mark.parametrize("sname", ["none", "multiplier"])
+def test_train_icrf_matches_reference_run(dev, sname):
+    """Five epochs of train_icrf (per-channel Adam, lr 1e-3, alpha 10) reproduce the curve the reference reached,
+    including its dead first step."""
+    from clair_torch_amd.common.enums import InterpMode, MissingStdMode
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.training import train_icrf
+    from oracle import ct_oracle as oc
+    g = golden("training")
+    x = torch.from_numpy(oc.normalize_codes(g["train_codes"]))
+    mode = MissingStdMode.MULTIPLIER if sname == "multiplier" else MissingStdMode.NONE
+    ds = StackDataset(x, g["train_exposures"].tolist(), missing_std_mode=mode, missing_std_value=0.05)
+    loader = DataLoader(ds, batch_size=x.shape[0], shuffle=False, collate_fn=custom_collate)
+    model = ICRFModelDirect(n_points=256, channels=3, interpolation_mode=InterpMode.LINEAR, initial_power=2.5).to(dev)
+    opts = [torch.optim.Adam(model.channel_params(c), lr=1e-3, amsgrad=False) for c in range(3)]
+    out = train_icrf(loader, x.shape[0], "cuda", model, optimizers=opts, schedulers=None,
+                     use_relative_linearity_loss=True, use_uncertainty_weighting=False, epochs=5, patience=200,
+                     alpha=10.0, beta=1.0, gamma=1.0, delta=1.0, lower_valid_threshold=1 / 255,
+                     upper_valid_threshold=254 / 255, exposure_ratio_threshold=0.25, verbose=False)
+    assert out is model
+    ref = g[f"trainloop_{sname}_nounc_icrf"]
+    got = model.icrf.detach().cpu().numpy()
+    # Adam's first steps move every bin by ~lr regardless of the gradient's size, so agreement to 2e-6 absolute
+    # (0.2 % of one step) means every bin's gradient sign and relative size matched the reference
+    assert np.max(np.abs(got - ref)) < 2e-6, np.max(np.abs(got - ref))
+    assert sorted(model.state_dict().keys()) == sorted(
+        ["_x_axis_datapoints", "_icrf", "direct_params.0", "direct_params.1", "direct_params.2"])
+
+
+def test_train_icrf_argument_errors(dev):
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.training import train_icrf
+    ds = StackDataset(torch.rand(4, 3, 8, 8), [1, 2, 3, 4])
+    loader = DataLoader(ds, batch_size=4, collate_fn=custom_collate)
+    model = ICRFModelDirect().to(dev)
+    with pytest.raises(ValueError, match="larger than 1"):
+        train_icrf(loader, 1, "cuda", model)
+    opts = [torch.optim.Adam(model.channel_params(c)) for c in range(3)]
+    with pytest.raises(ValueError, match="Mismatched number"):
+        train_icrf(loader, 4, "cuda", model, optimizers=opts, schedulers=[None])
+    with pytest.raises(RuntimeError, match="MI355X"):
+        train_icrf(loader, 4, "cpu", model)

@@ -1,0 +1,104 @@
+// merge_bench.hip -- development harness: times instantiations <V, PF> of the PRODUCT merge kernel
+// (csrc/ct_merge.hip is included verbatim) on the C2 shape, interleaved rounds in one process.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/merge_bench.hip \
+//         clair_torch_amd/csrc/ct_api.cpp -o tools/merge_bench
+#include "../clair_torch_amd/csrc/ct_merge.hip"
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_random(uint16_t *p, size_t n, uint32_t seed, int mode, size_t Q)
+{
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t h = (uint32_t)(i % Q) * 2654435761u + seed;
+        h ^= h >> 16; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        if (mode == 0) {
+            uint32_t g = (uint32_t)i * 2654435761u + seed; g ^= g >> 16; g *= 2246822519u; g ^= g >> 13;
+            p[i] = (uint16_t)(g >> 8);
+        } else {
+            int nn = (int)(i / Q);
+            float E = (h >> 8) * (1.0f / 16777216.0f) * 2.0f / 0.0146f;
+            float t = 0.001f * exp2f(nn * 0.25f);
+            float lin = fminf(E * t, 1.0f);
+            p[i] = (uint16_t)rintf(powf(lin, 1.0f / 2.2f) * 65535.0f);
+        }
+    }
+}
+
+using namespace ct;
+struct Variant { std::string name; void (*launch)(const MergeArgs &, hipStream_t); };
+
+template <int V, int PF, int STD, int MOM = 1>
+void launch_v(const MergeArgs &a0, hipStream_t s)
+{
+    MergeArgs a = a0;
+    const uint32_t vecs = a.q_count / V, grid = (vecs + kBlock - 1) / kBlock;
+    const size_t lds = (size_t)a.channels * a.n_points * lut_entry_bytes(CT_INTERP_LINEAR) + 2 * sizeof(float) * (size_t)a.batch;
+    hipLaunchKernelGGL((merge_kernel<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, true, PF, MOM>), dim3(grid), dim3(kBlock), lds, s, a);
+}
+
+int main(int argc, char **argv)
+{
+    int N = argc > 1 ? atoi(argv[1]) : 32, H = argc > 2 ? atoi(argv[2]) : 4096, Wd = argc > 3 ? atoi(argv[3]) : 4096;
+    int rounds = argc > 4 ? atoi(argv[4]) : 7;
+    const size_t Q = (size_t)3 * H * Wd, S = Q * N;
+    uint16_t *stack; float *lut; double *expo; double *mean; float *stdo;
+    CK(hipMalloc(&stack, S * 2)); CK(hipMalloc(&lut, 768 * 4)); CK(hipMalloc(&expo, N * 8));
+    CK(hipMalloc(&mean, Q * 8)); CK(hipMalloc(&stdo, Q * 4));
+    std::vector<float> hl(768); std::vector<double> he(N);
+    const double pw[3] = {2.2, 2.4, 2.6};
+    for (int r = 0; r < 3; ++r) for (int i = 0; i < 256; ++i) hl[r * 256 + i] = (float)pow(i / 255.0, pw[r]);
+    for (int n = 0; n < N; ++n) he[n] = 0.001 * pow(2.0, n / 4.0);
+    CK(hipMemcpy(lut, hl.data(), 768 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(expo, he.data(), N * 8, hipMemcpyHostToDevice));
+    MergeArgs a{};
+    a.stack = stack; a.exposure = expo; a.lut = lut; a.mean_out = mean; a.std_out = stdo;
+    a.image_stride = (int64_t)Q; a.q_begin = 0; a.q_count = (uint32_t)Q;
+    a.tile.plane_local = (uint32_t)((size_t)H * Wd); a.tile.chan_skip = 0; a.tile.base = 0;
+    a.batch = N; a.channels = 3; a.n_points = 256;
+    ct_norm_constants(65535.0f, &a.norm.hi, &a.norm.lo);
+    if (ct_index_constants(65535.0f, 256, &a.index.hi, &a.index.lo) != CT_OK) { printf("fold refused\n"); return 1; }
+    a.inv_max_code = (float)(1.0 / 65535.0); a.std_value = 0.05f; a.weight_scale = 30.0f;
+    a.flags = CT_MERGE_FIRST_BATCH | CT_MERGE_FINALIZE;
+
+    std::vector<Variant> vs = {
+        {"V8 PF2 f64", launch_v<8, 2, CT_STD_MULTIPLIER, 0>}, {"V4 PF2 f64", launch_v<4, 2, CT_STD_MULTIPLIER, 0>},
+        {"V8 PF1 blk", launch_v<8, 1, CT_STD_MULTIPLIER, 1>}, {"V8 PF2 blk", launch_v<8, 2, CT_STD_MULTIPLIER, 1>},
+        {"V4 PF1 blk", launch_v<4, 1, CT_STD_MULTIPLIER, 1>}, {"V4 PF2 blk", launch_v<4, 2, CT_STD_MULTIPLIER, 1>},
+        {"V4 PF3 blk", launch_v<4, 3, CT_STD_MULTIPLIER, 1>}, {"V2 PF2 blk", launch_v<2, 2, CT_STD_MULTIPLIER, 1>},
+        {"V8 PF2 nostd", launch_v<8, 2, CT_STD_NONE>}, {"V4 PF2 nostd", launch_v<4, 2, CT_STD_NONE>},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double bytes = (double)S * 2 + (double)Q * 12;
+    for (int mode = 0; mode < 2; ++mode) {
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, stack, S, 12345u, mode, Q);
+        CK(hipDeviceSynchronize());
+        printf("== data: %s, N=%d %dx%d, algorithmic bytes %.3f GB ==\n", mode == 0 ? "uniform random codes" : "gamma-2.2 scene", N, H, Wd, bytes / 1e9);
+        std::vector<std::vector<float>> ms(vs.size());
+        for (int r = 0; r < rounds + 1; ++r)
+            for (size_t v = 0; v < vs.size(); ++v) {
+                CK(hipEventRecord(e0, 0));
+                vs[v].launch(a, 0);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                if (r > 0) ms[v].push_back(t);
+            }
+        CK(hipGetLastError());
+        for (size_t v = 0; v < vs.size(); ++v) {
+            std::sort(ms[v].begin(), ms[v].end());
+            float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
+            printf("%-16s med %.3f ms  min %.3f ms  %.2f TB/s  %.1f%% of 8TB/s  %.0f MPix/s\n", vs[v].name.c_str(), med, mn,
+                   bytes / med / 1e9, bytes / med / 1e9 / 8.0 * 100, (double)H * Wd / med / 1e3);
+        }
+    }
+    std::vector<float> hs(16); CK(hipMemcpy(hs.data(), stdo, 64, hipMemcpyDeviceToHost));
+    printf("std[0..3] = %g %g %g %g\n", hs[0], hs[1], hs[2], hs[3]);
+    return 0;
+}
