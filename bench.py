@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the hot path on MI355X, one JSON line on stdout (rank 0).
+
+Default workload = BASELINE.json config C2: HDR merge + propagated uncertainty of a 32-exposure 4096x4096x3 uint16
+stack (LINEAR ICRF, Gaussian weights, sigma = 0.05 * x derived in-kernel), inputs resident in HBM.
+A "step" is one ct_hdr_merge_batch launch over the whole stack.  With --gpus N every rank merges its own C2-sized row
+band of a (4096*N) x 4096 global image (weak scaling, no data-path collective: pixels are independent); a small RCCL
+all_gather of per-band statistics runs once after the timed region (the C5 "gather of per-tile stats").
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+The JSON carries `roofline` (HBM: algorithmic bytes / mean kernel time from device events on the launch stream, against
+the 8 TB/s spec peak) and `cpu_baseline` (the reference-equivalent eager-PyTorch path of oracle/eager_torch.py timed on
+the host cores over a bounded sample; N = 1, rank 0 only).  Other workloads (--workload linearize|train) are for
+development and print the same shape of line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+POWERS = (2.2, 2.4, 2.6)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may use: the scheduler affinity, capped at the 16-core share a one-GPU box grants
+    (os.cpu_count() reports the whole host, 256 logical CPUs, and oversubscribing them is 10x slower)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("CLAIR_BENCH_CORES", "16"))))
+
+
+def make_lut(device):
+    return torch.stack([torch.linspace(0, 1, 256) ** p for p in POWERS]).to(device)
+
+
+def cpu_baseline_merge(n_exp, stops, seconds=12.0, tile=512):
+    """Eager-PyTorch restatement (the reference's op sequence incl. autograd) on host cores, 512x512 tiles."""
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    from oracle import eager_torch as oe
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    lut = make_lut("cpu")
+    codes, exposures = synthetic_exposure_stack(n_exp, 3, tile, tile, bits=16, stops_per_step=stops, seed=1236)
+    x = codes.to(torch.int32).to(torch.float32) / 65535.0
+    sd = x * torch.tensor(0.05)
+    t = torch.tensor(exposures, dtype=torch.float64)
+    oe.merge_stack(x[:, :, :64, :64], sd[:, :, :64, :64], t, lut, "linear", True)  # warm the op caches
+    done, t0 = 0, time.perf_counter()
+    while True:
+        oe.merge_stack(x, sd, t, lut, "linear", True)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 64:
+            break
+    return {"value": round(done * tile * tile / el / 1e6, 4), "unit": "MPix/s", "cores": threads, "kind": "port",
+            "sample": f"{done} tile(s) of {n_exp}x{tile}x{tile}x3 float32 (same synthetic scene), single batch, "
+                      f"oracle/eager_torch.merge_stack incl. autograd variance, {el:.1f} s"}
+
+
+def run_merge(args, rank, world, dev):
+    from clair_torch_amd import ops
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    n_exp, h, w, c = args.exposures, args.height, args.width, 3
+    h_global = h * world
+    codes, exposures = synthetic_exposure_stack(n_exp, c, h_global, w, bits=16, stops_per_step=0.25, seed=1236,
+                                                device=dev, row_range=(rank * h, (rank + 1) * h))
+    lut = make_lut(dev)
+    t_dev = torch.tensor(exposures, dtype=torch.float64, device=dev)
+    tile = ops.TileGeometry(h_global=h_global, row_offset=rank * h) if world > 1 else None
+    kw = dict(lut=lut, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05, tile=tile)
+
+    def step():
+        return ops.hdr_merge_batch(codes, t_dev, **kw)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        mean, std = step()
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, world, dev)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    # per-band statistics gathered over RCCL (untimed; C5's "gather of per-tile stats")
+    stats = torch.stack([mean.amin(dim=(1, 2)), mean.amax(dim=(1, 2)), mean.sum(dim=(1, 2)),
+                         std.double().amin(dim=(1, 2)), std.double().amax(dim=(1, 2)), std.double().sum(dim=(1, 2))])
+    gathered = gather_stats(stats, world)
+    px = h * w
+    bytes_alg = n_exp * c * px * 2 + c * px * (8 + 4)  # uint16 stack read + float64 mean + float32 std written
+    out = {
+        "metric": "MPix/s HDR-merged (+uncertainty) at N=32 4K RGB", "value": round(world * px * args.steps / elapsed / 1e6, 1),
+        "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2: {n_exp}-exposure {h}x{w}x3 uint16 stack per GPU, merge+uncertainty "
+                               f"(LINEAR ICRF 3x256, Gaussian weights, sigma=0.05*x in-kernel, float64 mean + float32 std out)",
+                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel<uint16,4,LINEAR,GAUSS,MULTIPLIER>",
+                   "finite": bool(torch.isfinite(gathered).all())},
+        "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": measured_traffic("merge_c2"), "bytes_per_launch": bytes_alg,
+                     "kernel_ms": round(kernel_ms, 4)},
+    }
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        del codes
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_merge(n_exp, 0.25, args.cpu_seconds)
+    return out
+
+
+def run_linearize(args, rank, world, dev):
+    """C4: streamed 1920x1080x3 frames, kernel-only (frames resident), frames batched per launch."""
+    from clair_torch_amd import ops
+    frames = torch.randint(0, 65536, (args.frames, 3, 1080, 1920), device=dev, dtype=torch.int32).to(torch.uint16)
+    lut = make_lut(dev)
+    step = lambda: ops.linearize_frames(frames, lut, "linear", std_mode="multiplier", std_value=0.05)  # noqa: E731
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+    px = args.frames * 1080 * 1920
+    bytes_alg = px * 3 * (2 + 8)
+    return {"metric": "frames/s linearized (+uncertainty), 1920x1080x3 uint16, kernel-only", "unit": "frames/s",
+            "value": round(args.frames * args.steps / elapsed, 1), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4: {args.frames} resident 1920x1080x3 uint16 frames per launch, ct_linearize_std"},
+            "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None}}
+
+
+def run_train(args, rank, world, dev):
+    """C3: one train_icrf optimizer step (forward sums + LUT gradient + Adam) on a 64-exposure 2048x2048x3 stack."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    from clair_torch_amd.training import linearity_loss
+    n_exp, h, w = args.train_exposures, args.train_size, args.train_size
+    codes, exposures = synthetic_exposure_stack(n_exp, 3, h, w, bits=16, stops_per_step=0.125, seed=1237, device=dev)
+    t = torch.tensor(exposures, dtype=torch.float64)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n_exp, dev)
+    params = [torch.nn.Parameter((torch.linspace(0, 1, 256) ** 2.5).to(dev)) for _ in range(3)]
+    opts = [torch.optim.Adam([p], lr=1e-3) for p in params]
+
+    def step():
+        for o in opts:
+            o.zero_grad()
+        lut = torch.stack(params)
+        lin, _ = linearity_loss(lut, codes, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
+                                use_unc_weight=False)
+        lin.sum().backward()
+        for o in opts:
+            o.step()
+        return lin
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return {"metric": "ICRF training iterations/s (linearity term fwd+bwd + Adam)", "unit": "iters/s",
+            "value": round(args.steps / elapsed, 3), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: {n_exp}-exposure {h}x{w}x3 uint16 stack, {pairs.n_pairs} pairs, relative loss"},
+            "roofline": {"bound": "valu", "achieved": None, "peak": 157.3, "unit": "TFLOP/s", "frac": None, "traffic": None}}
+
+
+def measured_traffic(key):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 FETCH_SIZE/WRITE_SIZE, gfx950
+    correction applied there); None when no profile for this workload exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def barrier(world):
+    if world > 1:
+        torch.distributed.barrier()
+
+
+def max_over_ranks(value, world, dev):
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_stats(stats, world):
+    if world == 1:
+        return stats.unsqueeze(0)
+    out = [torch.empty_like(stats) for _ in range(world)]
+    torch.distributed.all_gather(out, stats.contiguous())
+    return torch.stack(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="merge", choices=["merge", "linearize", "train"])
+    ap.add_argument("--exposures", type=int, default=32)
+    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--train-exposures", type=int, default=64)
+    ap.add_argument("--train-size", type=int, default=2048)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                             f"(WORLD_SIZE is {world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    from clair_torch_amd import _native
+    _native.load()
+    fn = {"merge": run_merge, "linearize": run_linearize, "train": run_train}[args.workload]
+    out = fn(args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,10 +33,10 @@ def lib():
         i64, i32, f32, f64, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
         L.cto_normalize_u8.argtypes = [vp, i64, vp]
         L.cto_normalize_u16.argtypes = [vp, i64, vp]
-        L.cto_icrf_forward.argtypes = [vp, i64, i32, i64, i64, vp, i32, i32, vp, vp]
-        L.cto_hdr_merge_batch.argtypes = [vp, vp, vp, i64, i32, i64, i64, vp, i32, i32, i32, vp, vp, vp, i32]
+        L.cto_icrf_forward.argtypes = [vp, i64, i32, i64, i64, vp, i32, i32, vp, vp, i64, i64]
+        L.cto_hdr_merge_batch.argtypes = [vp, vp, vp, i64, i32, i64, i64, vp, i32, i32, i32, vp, vp, vp, i32, i64, i64]
         L.cto_hdr_merge_batch.restype = i32
-        L.cto_linearize_std.argtypes = [vp, vp, i64, i32, i64, i64, vp, i32, i32, vp, vp]
+        L.cto_linearize_std.argtypes = [vp, vp, i64, i32, i64, i64, vp, i32, i32, vp, vp, i64, i64]
         L.cto_linearize_std.restype = i32
         L.cto_pair_sums.argtypes = [vp, vp, vp, i64, i32, i64, i64, vp, vp, vp, i64, f32, f32, i32, i32, vp]
         _lib = L
@@ -64,13 +64,18 @@ def normalize_codes(u):
     return x
 
 
-def icrf_forward(x, lut, mode, want_derivative=False):
+def _geom(tile):
+    """tile = None (whole image) or (h_global, row_offset) for a band of rows of a taller image."""
+    return (0, 0) if tile is None else (int(tile[0]), int(tile[1]))
+
+
+def icrf_forward(x, lut, mode, want_derivative=False, tile=None):
     x = _f32(x)
     n, c, h, w = x.shape
     lut = _f32(lut)
     out = np.empty_like(x)
     dout = np.empty_like(x) if want_derivative else None
-    lib().cto_icrf_forward(_p(x), n, c, h, w, _p(lut), lut.shape[1], MODES[mode], _p(out), _p(dout))
+    lib().cto_icrf_forward(_p(x), n, c, h, w, _p(lut), lut.shape[1], MODES[mode], _p(out), _p(dout), *_geom(tile))
     return (out, dout) if want_derivative else out
 
 
@@ -86,7 +91,7 @@ class MergeState:
         self.has_var = False
 
 
-def hdr_merge_batch(state, x, sd, exposures, lut, mode, use_gauss):
+def hdr_merge_batch(state, x, sd, exposures, lut, mode, use_gauss, tile=None):
     x = _f32(x)
     sd = _f32(sd)
     b, c, h, w = x.shape
@@ -95,7 +100,7 @@ def hdr_merge_batch(state, x, sd, exposures, lut, mode, use_gauss):
     L = 0 if lut_c is None else lut_c.shape[1]
     m = MODES["nomodel"] if lut_c is None else MODES[mode]
     rc = lib().cto_hdr_merge_batch(_p(x), _p(sd), _p(t), b, c, h, w, _p(lut_c), L, m, int(bool(use_gauss)),
-                                   _p(state.mean), _p(state.sumw), _p(state.var), int(state.first))
+                                   _p(state.mean), _p(state.sumw), _p(state.var), int(state.first), *_geom(tile))
     if rc != 0:
         raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
     state.first = False
@@ -103,24 +108,24 @@ def hdr_merge_batch(state, x, sd, exposures, lut, mode, use_gauss):
     return state
 
 
-def hdr_merge(x, sd, exposures, lut, mode="linear", use_gauss=True, partition=None):
+def hdr_merge(x, sd, exposures, lut, mode="linear", use_gauss=True, partition=None, tile=None):
     """Whole compute_hdr_image for an in-memory stack; ``partition`` = batch sizes (default one batch)."""
     n, c, h, w = x.shape
     partition = [n] if partition is None else list(partition)
     st, k = MergeState(c, h, w), 0
     for b in partition:
-        hdr_merge_batch(st, x[k:k + b], None if sd is None else sd[k:k + b], exposures[k:k + b], lut, mode, use_gauss)
+        hdr_merge_batch(st, x[k:k + b], None if sd is None else sd[k:k + b], exposures[k:k + b], lut, mode, use_gauss, tile)
         k += b
     return st.mean, (np.sqrt(st.var) if st.has_var else None)
 
 
-def linearize_std(x, sd, lut, mode="linear"):
+def linearize_std(x, sd, lut, mode="linear", tile=None):
     x = _f32(x)
     sd = _f32(sd)
     f, c, h, w = x.shape
     lut = _f32(lut)
     lin, so = np.empty_like(x), np.empty_like(x)
-    rc = lib().cto_linearize_std(_p(x), _p(sd), f, c, h, w, _p(lut), lut.shape[1], MODES[mode], _p(lin), _p(so))
+    rc = lib().cto_linearize_std(_p(x), _p(sd), f, c, h, w, _p(lut), lut.shape[1], MODES[mode], _p(lin), _p(so), *_geom(tile))
     if rc != 0:
         raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
     return lin, so

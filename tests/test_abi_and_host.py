@@ -1,0 +1,255 @@
+"""CPU tests: the C-ABI library loads and exports every symbol of include/clair_hip.h, argument validation that
+returns before any launch, the host-side code-normalisation proofs, and the host logic around the kernels
+(collation, datasets, transform fusion, pair lists, loud failure without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from clair_torch_amd import build, _native
+    build.build()
+    return _native.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, "include", "clair_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ct_[a-z_0-9]+)\s*\(", header))
+    assert {"ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd", "ct_linearize_bwd", "ct_pair_residual_fwd",
+            "ct_pair_residual_bwd", "ct_abi_version", "ct_error_string"} <= declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in clair_hip.h but not exported"
+    assert lib.ct_abi_version() == 1
+    assert lib.ct_error_string(0) == b"ok" and b"gradient" in lib.ct_error_string(-4)
+
+
+def test_argument_validation_returns_before_launch(lib):
+    from clair_torch_amd import _native as nv
+    g = nv.Geometry(channels=3, h_tile=4, width=4, h_global=4, row_offset=0, image_stride=48)
+    icrf = nv.Icrf(lut_dev=None, n_points=0, interp=nv.INTERP_NONE)
+    fake = ctypes.c_void_p(0x1000)  # never dereferenced: validation fails first
+    rc = lib.ct_hdr_merge_batch(None, nv.DTYPE_F32, 1.0, 4, ctypes.byref(g), None, nv.STD_NONE, 0.0, fake,
+                                ctypes.byref(icrf), nv.WEIGHT_NONE, None, None, None, fake, None, 3, None)
+    assert rc == -1
+    lut = nv.Icrf(lut_dev=0x1000, n_points=256, interp=nv.INTERP_LOOKUP)
+    rc = lib.ct_hdr_merge_batch(fake, nv.DTYPE_F32, 1.0, 4, ctypes.byref(g), None, nv.STD_CONSTANT, 0.1, fake,
+                                ctypes.byref(lut), nv.WEIGHT_NONE, None, None, None, fake, fake, 3, None)
+    assert rc == nv.ERR_NO_GRADIENT_PATH  # hdr_merge.py:107-113 raises in the reference
+    bad = nv.Geometry(channels=3, h_tile=4, width=4, h_global=2, row_offset=0, image_stride=48)
+    rc = lib.ct_linearize_std(fake, nv.DTYPE_F32, 1.0, 1, ctypes.byref(bad), None, nv.STD_NONE, 0.0, ctypes.byref(lut),
+                              fake, None, None)
+    assert rc == -1
+    with pytest.raises(RuntimeError, match="does not require grad"):
+        nv.check(nv.ERR_NO_GRADIENT_PATH, "x")
+    with pytest.raises(ValueError):
+        nv.check(-1, "x")
+
+
+@pytest.mark.parametrize("max_code", [255, 1023, 4095, 65535])
+def test_code_normalisation_constants_are_exact(lib, max_code):
+    """fma(u, hi, u*lo) == float32(u) / float32(max_code) for every code (the reference's Normalize)."""
+    hi, lo = ctypes.c_float(), ctypes.c_float()
+    lib.ct_norm_constants.argtypes = [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    assert lib.ct_norm_constants(float(max_code), ctypes.byref(hi), ctypes.byref(lo)) == 0
+    u = np.arange(max_code + 1, dtype=np.float32)
+    ref = u / np.float32(max_code)
+    got = (u.astype(np.float64) * np.float64(hi.value) + (u * np.float32(lo.value)).astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, ref)
+    lib.ct_index_constants.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                       ctypes.POINTER(ctypes.c_float)]
+    rc = lib.ct_index_constants(float(max_code), 256, ctypes.byref(hi), ctypes.byref(lo))
+    if rc == 0:  # the folded LUT coordinate must select the reference's interval for every code
+        s_new = (u.astype(np.float64) * np.float64(hi.value) + (u * np.float32(lo.value)).astype(np.float64)).astype(np.float32)
+        s_ref = ref * np.float32(255.0)
+        assert np.array_equal(np.floor(s_new), np.floor(s_ref))
+    assert lib.ct_norm_constants(0.5, ctypes.byref(hi), ctypes.byref(lo)) != 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from clair_torch_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native._build, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.load()
+
+
+def test_cpu_device_is_refused_loudly():
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.inference import compute_hdr_image, linearize_dataset_generator
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd import ops
+    ds = StackDataset(torch.rand(4, 3, 8, 8), [1, 2, 3, 4])
+    loader = DataLoader(ds, batch_size=2, collate_fn=custom_collate)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        compute_hdr_image(loader, "cpu", ICRFModelDirect())
+    with pytest.raises(RuntimeError, match="MI355X"):
+        next(iter(linearize_dataset_generator(DataLoader(ds, batch_size=1, collate_fn=custom_collate), "cpu",
+                                              ICRFModelDirect())))
+    with pytest.raises(RuntimeError, match="cuda"):
+        ICRFModelDirect()(torch.rand(1, 3, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.hdr_merge_batch(torch.rand(2, 3, 4, 4), torch.tensor([1.0, 2.0]))
+
+
+def test_entry_point_type_errors():
+    from clair_torch_amd.common.typecheck import TypeCheckError
+    from clair_torch_amd.inference import compute_hdr_image
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.common.enums import InterpMode
+    with pytest.raises(TypeCheckError):
+        compute_hdr_image([1, 2, 3], "cuda")
+    with pytest.raises(TypeCheckError):
+        ICRFModelDirect(interpolation_mode="linear")
+    assert ICRFModelDirect(interpolation_mode=InterpMode.CATMULL).interp_name == "catmull"
+
+
+def test_custom_collate_semantics():
+    """Sorted by exposure time, float64 exposure tensor, std batch None if any std is missing (collate.py:8-43)."""
+    from clair_torch_amd.datasets import custom_collate
+    items = [(0, torch.full((1, 2, 2), 3.0), torch.ones(1, 2, 2), {"exposure_time": 0.3}),
+             (1, torch.full((1, 2, 2), 1.0), torch.ones(1, 2, 2), {"exposure_time": 0.1}),
+             (2, torch.full((1, 2, 2), 2.0), None, {"exposure_time": 0.2})]
+    idx, val, std, meta = custom_collate(items)
+    assert idx.tolist() == [1, 2, 0] and val[:, 0, 0, 0].tolist() == [1.0, 2.0, 3.0]
+    assert std is None and meta["exposure_time"].dtype == torch.float64
+    _, _, std2, _ = custom_collate(items[:2])
+    assert std2.shape == (2, 1, 2, 2)
+
+
+def test_stack_dataset_std_modes_and_uint16_collation():
+    from clair_torch_amd.common.enums import MissingStdMode
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    x = torch.rand(3, 3, 4, 4)
+    ds = StackDataset(x, [1, 2, 3], missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05)
+    _, v, s, m = ds[1]
+    assert torch.equal(s, v * torch.tensor(0.05)) and m == {"exposure_time": 2.0} and ds.std_hint is None
+    ds = StackDataset(x, [1, 2, 3], missing_std_mode=MissingStdMode.CONSTANT, missing_std_value=0.01)
+    assert torch.equal(ds[0][2], torch.full_like(x[0], 0.01))
+    codes = torch.randint(0, 65535, (3, 3, 4, 4), dtype=torch.int32).to(torch.uint16)
+    ds = StackDataset(codes, [3, 1, 2], missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05,
+                      materialize_std=False)
+    assert ds.std_hint == ("multiplier", 0.05) and ds[0][2] is None
+    _, val, std, meta = next(iter(DataLoader(ds, batch_size=3, collate_fn=custom_collate)))
+    assert val.dtype == torch.uint16 and std is None and meta["exposure_time"].tolist() == [1.0, 2.0, 3.0]
+    assert torch.equal(val[0].to(torch.int32), codes[1].to(torch.int32))
+    with pytest.raises(ValueError):
+        StackDataset(x, [1, 2])
+
+
+def test_transform_fusion_detection():
+    from clair_torch_amd.common.transforms import CastTo, Normalize, fusable_code_normalisation
+    codes = torch.zeros((1, 3, 2, 2), dtype=torch.uint16)
+    assert fusable_code_normalisation(codes, [CastTo("float32"), Normalize(max_val=65535, min_val=0)]) == 65535.0
+    assert fusable_code_normalisation(codes, [CastTo("float32"), Normalize(4095, 0)]) == 4095.0
+    assert fusable_code_normalisation(codes, [Normalize(65535, 0)]) is None          # no cast: not the reference's chain
+    assert fusable_code_normalisation(codes, [CastTo("float64"), Normalize(65535, 0)]) is None
+    assert fusable_code_normalisation(codes, [CastTo("float32"), Normalize(65535, 1)]) is None
+    assert fusable_code_normalisation(codes, [CastTo("float32"), Normalize(65535, 0, (0, 2))]) is None
+    assert fusable_code_normalisation(codes.float(), [CastTo("float32"), Normalize(65535, 0)]) is None
+    x = torch.tensor([0.0, 128.0, 255.0])
+    assert torch.equal(Normalize(255, 0)(x), x / 255)
+    with pytest.raises(ValueError):
+        Normalize()(torch.ones(3))
+
+
+def test_exposure_pairs_and_partner_lists():
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_pairwise_valid_pixel_mask, get_valid_exposure_pairs
+    i, j, r = get_valid_exposure_pairs(torch.tensor([1.0, 2.0, 4.0]), 0.4)   # reference test_general_functions.py:290-327
+    assert i.tolist() == [0, 1] and j.tolist() == [1, 2] and r.tolist() == [0.5, 0.5]
+    i, j, r = get_valid_exposure_pairs(torch.tensor([1.0, 2.0, 4.0]))
+    assert i.tolist() == [0, 0, 1] and j.tolist() == [1, 2, 2] and r.tolist() == [0.5, 0.25, 0.5]
+    pl = ops.PairList(i, j, r, 3, "cpu")
+    assert pl.part_off.tolist() == [0, 2, 4, 6]
+    assert pl.part_sample.tolist() == [1, 2, 0, 2, 0, 1]
+    assert pl.part_pair.tolist() == [0, 1, ~0, 2, ~1, ~2]
+    stack = torch.tensor([0.0, 0.5, 1.0]).view(3, 1, 1, 1)
+    m = get_pairwise_valid_pixel_mask(stack, i, j, val_lower=0.1, val_upper=0.9)
+    assert m.flatten().tolist() == [False, False, False]
+    with pytest.raises(ValueError):
+        get_pairwise_valid_pixel_mask(stack, i, j, val_lower=1.0, val_upper=0.0)
+
+
+def test_penalties_match_eager_oracle_and_gaussian_weights():
+    from clair_torch_amd.training import losses
+    from oracle import eager_torch as oe
+    curve = torch.stack([torch.linspace(0, 1, 32) ** 2, torch.linspace(-0.1, 1.2, 32), torch.linspace(1, 0, 32)])
+    mono, rng, endp, smooth = oe.curve_penalties(curve)
+    assert torch.equal(losses.compute_monotonicity_penalty(curve, per_channel=True), mono)
+    assert torch.equal(losses.compute_range_penalty(curve, per_channel=True), rng)
+    assert torch.equal(losses.compute_endpoint_penalty(curve, per_channel=True), endp)
+    assert torch.equal(losses.compute_smoothness_penalty(curve, per_channel=True), smooth)
+    assert torch.equal(losses.compute_smoothness_penalty(curve), smooth.sum())
+    x = torch.linspace(0, 1, 11)
+    w = losses.gaussian_value_weights(x)                       # reference test_losses.py:10-60
+    assert w[5] == 1.0 and torch.allclose(w, w.flip(0)) and (w <= 1).all() and (w > 0).all()
+    assert (losses.gaussian_value_weights(x, 10.0) >= w).all()
+    pw = losses.combined_gaussian_pair_weights(x.view(-1, 1), torch.tensor([0, 1]), torch.tensor([2, 3]), 10.0)
+    assert torch.equal(pw[0], losses.gaussian_value_weights(x[0:1], 10.0) + losses.gaussian_value_weights(x[2:3], 10.0))
+
+
+def test_model_state_dict_and_default_curve():
+    from clair_torch_amd.models import ICRFModelDirect
+    m = ICRFModelDirect(n_points=16, channels=2, initial_power=2.0)
+    assert sorted(m.state_dict()) == ["_icrf", "_x_axis_datapoints", "direct_params.0", "direct_params.1"]
+    assert torch.equal(m.icrf, (torch.linspace(0, 1, 16) ** 2.0).repeat(2, 1))
+    assert m.channel_params(1)[0] is m.direct_params[1]
+    m.update_icrf()
+    assert m.icrf.requires_grad and m.icrf.shape == (2, 16)
+    given = torch.rand(3, 8)
+    m2 = ICRFModelDirect(icrf=given.clone())
+    assert m2.channels == 3 and m2.n_points == 8 and torch.equal(m2.icrf, given)
+    m2.load_state_dict(ICRFModelDirect(icrf=given * 0.5).state_dict())
+    assert torch.equal(m2.icrf, given * 0.5)
+    assert m.plot_icrf() is None
+
+
+def test_synthetic_stack_bands_assemble_to_the_whole():
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    whole, t = synthetic_exposure_stack(4, 3, 24, 10, bits=16, seed=5)
+    parts = [synthetic_exposure_stack(4, 3, 24, 10, bits=16, seed=5, row_range=r)[0] for r in ((0, 7), (7, 24))]
+    assert torch.equal(torch.cat(parts, dim=2).to(torch.int32), whole.to(torch.int32))
+    assert whole.dtype == torch.uint16 and t == [1e-3 * 2 ** (k * 0.25) for k in range(4)]
+    u8, _ = synthetic_exposure_stack(3, 1, 8, 8, bits=8)
+    assert u8.dtype == torch.uint8 and 0 < u8.float().mean() < 255
+
+
+def test_reference_import_paths_resolve():
+    import clair_torch  # noqa: F401
+    from clair_torch.inference.hdr_merge import compute_hdr_image
+    from clair_torch.inference.linearization import linearize_dataset_generator
+    from clair_torch.inference.measure_linearity import measure_linearity
+    from clair_torch.models.icrf_model import ICRFModelDirect
+    from clair_torch.training.icrf_training import train_icrf
+    from clair_torch.training.losses import gaussian_value_weights
+    from clair_torch.datasets.collate import custom_collate
+    from clair_torch.common.enums import InterpMode
+    assert all(callable(f) for f in (compute_hdr_image, linearize_dataset_generator, measure_linearity, train_icrf,
+                                     gaussian_value_weights, custom_collate))
+    assert ICRFModelDirect and InterpMode.LINEAR
+
+
+def test_oracle_tiles_equal_whole():
+    """The oracle's own tile geometry (used by the sharding tests): bands with global geometry == whole image."""
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(3)
+    x = rng.random((4, 3, 9, 7), dtype=np.float32)
+    lut = np.stack([np.linspace(0, 1, 32, dtype=np.float32) ** np.float32(p) for p in (1.5, 2.0, 2.5)])
+    t = np.array([1.0, 2.0, 4.0, 8.0])
+    sd = x * np.float32(0.05)
+    mean, std = oc.hdr_merge(x, sd, t, lut, "linear", True)
+    for r0, r1 in ((0, 4), (4, 9)):
+        m_t, s_t = oc.hdr_merge(np.ascontiguousarray(x[:, :, r0:r1]), np.ascontiguousarray(sd[:, :, r0:r1]), t, lut,
+                                "linear", True, tile=(9, r0))
+        assert np.array_equal(m_t, mean[:, r0:r1]) and np.array_equal(s_t, std[:, r0:r1])
+    m_bad, _ = oc.hdr_merge(np.ascontiguousarray(x[:, :, 4:9]), np.ascontiguousarray(sd[:, :, 4:9]), t, lut, "linear", True)
+    assert not np.array_equal(m_bad, mean[:, 4:9])

@@ -32,16 +32,45 @@ __global__ void fill_random(uint16_t *p, size_t n, uint32_t seed, int mode, size
     }
 }
 
+// streaming yardstick with the product kernel's access pattern: V uint16 per lane per exposure, 12 B written per element
+template <int V>
+__global__ __launch_bounds__(256) void stream_only(const ct::MergeArgs a)
+{
+    const uint32_t vec = blockIdx.x * 256u + threadIdx.x;
+    if (vec * V >= a.q_count) return;
+    const uint32_t q0 = vec * V;
+    uint32_t acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0;
+    const uint16_t *src = static_cast<const uint16_t *>(a.stack) + q0;
+#pragma unroll 4
+    for (int n = 0; n < a.batch; ++n) {
+        const ct::Packet<uint16_t, V> pk = *reinterpret_cast<const ct::Packet<uint16_t, V> *>(src + (int64_t)n * a.image_stride);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += pk.v[e];
+    }
+    ct::Packet<double, V> mo; ct::Packet<float, V> so;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { mo.v[e] = (double)acc[e]; so.v[e] = (float)acc[e]; }
+    *reinterpret_cast<ct::Packet<double, V> *>(static_cast<double *>(a.mean_out) + q0) = mo;
+    *reinterpret_cast<ct::Packet<float, V> *>(a.std_out + q0) = so;
+}
+template <int V> void launch_stream(const ct::MergeArgs &a, hipStream_t s)
+{
+    uint32_t vecs = a.q_count / V, grid = (vecs + 255) / 256;
+    hipLaunchKernelGGL((stream_only<V>), dim3(grid), dim3(256), 0, s, a);
+}
+
 using namespace ct;
 struct Variant { std::string name; void (*launch)(const MergeArgs &, hipStream_t); };
 
-template <int V, int PF, int STD, int MOM = 1>
+template <int V, int PF, int STD>
 void launch_v(const MergeArgs &a0, hipStream_t s)
 {
     MergeArgs a = a0;
     const uint32_t vecs = a.q_count / V, grid = (vecs + kBlock - 1) / kBlock;
     const size_t lds = (size_t)a.channels * a.n_points * lut_entry_bytes(CT_INTERP_LINEAR) + 2 * sizeof(float) * (size_t)a.batch;
-    hipLaunchKernelGGL((merge_kernel<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, true, PF, MOM>), dim3(grid), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((merge_kernel<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, true, PF>), dim3(grid), dim3(kBlock), lds, s, a);
 }
 
 int main(int argc, char **argv)
@@ -68,10 +97,10 @@ int main(int argc, char **argv)
     a.flags = CT_MERGE_FIRST_BATCH | CT_MERGE_FINALIZE;
 
     std::vector<Variant> vs = {
-        {"V8 PF2 f64", launch_v<8, 2, CT_STD_MULTIPLIER, 0>}, {"V4 PF2 f64", launch_v<4, 2, CT_STD_MULTIPLIER, 0>},
-        {"V8 PF1 blk", launch_v<8, 1, CT_STD_MULTIPLIER, 1>}, {"V8 PF2 blk", launch_v<8, 2, CT_STD_MULTIPLIER, 1>},
-        {"V4 PF1 blk", launch_v<4, 1, CT_STD_MULTIPLIER, 1>}, {"V4 PF2 blk", launch_v<4, 2, CT_STD_MULTIPLIER, 1>},
-        {"V4 PF3 blk", launch_v<4, 3, CT_STD_MULTIPLIER, 1>}, {"V2 PF2 blk", launch_v<2, 2, CT_STD_MULTIPLIER, 1>},
+        {"stream V4 (8B/lane)", launch_stream<4>}, {"stream V8 (16B/lane)", launch_stream<8>},
+        {"V8 PF1 mult", launch_v<8, 1, CT_STD_MULTIPLIER>}, {"V8 PF2 mult", launch_v<8, 2, CT_STD_MULTIPLIER>},
+        {"V4 PF1 mult", launch_v<4, 1, CT_STD_MULTIPLIER>}, {"V4 PF2 mult", launch_v<4, 2, CT_STD_MULTIPLIER>},
+        {"V4 PF3 mult", launch_v<4, 3, CT_STD_MULTIPLIER>},
         {"V8 PF2 nostd", launch_v<8, 2, CT_STD_NONE>}, {"V4 PF2 nostd", launch_v<4, 2, CT_STD_NONE>},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
