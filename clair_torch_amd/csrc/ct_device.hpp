@@ -44,7 +44,9 @@ __device__ __host__ __forceinline__ constexpr int lut_entry_bytes(int interp)
     return interp == CT_INTERP_LINEAR ? 8 : (interp == CT_INTERP_CATMULL ? 16 : 4);
 }
 
-template <int INTERP>
+// DELTA (LINEAR only): store {g[i], g[i+1] - g[i]} instead of {g[i], g[i+1]} -- the merge kernel's FMA lerp and its
+// derivative both want the difference (the float32 subtraction is the same one the reference's backward performs).
+template <int INTERP, bool DELTA = false>
 __device__ __forceinline__ void stage_lut(char *lds, const float *__restrict__ lut, int C, int L)
 {
     if constexpr (INTERP == CT_INTERP_NONE) {
@@ -56,7 +58,7 @@ __device__ __forceinline__ void stage_lut(char *lds, const float *__restrict__ l
             const float *row = lut + (size_t)r * L;
             const int im = i > 0 ? i - 1 : 0, i1 = i + 1 < L ? i + 1 : L - 1, i2 = i + 2 < L ? i + 2 : L - 1;
             if constexpr (INTERP == CT_INTERP_LINEAR) {
-                reinterpret_cast<float2 *>(lds)[k] = make_float2(row[i], row[i1]);
+                reinterpret_cast<float2 *>(lds)[k] = make_float2(row[i], DELTA ? row[i1] - row[i] : row[i1]);
             } else if constexpr (INTERP == CT_INTERP_CATMULL) {
                 reinterpret_cast<float4 *>(lds)[k] = make_float4(row[im], row[i], row[i1], row[i2]);
             } else {
@@ -142,6 +144,31 @@ __device__ __forceinline__ int lut_row(uint32_t q_global, int channel, int C)
         return channel;
     else
         return (int)(q_global % (uint32_t)C);
+}
+
+// Streaming store of a whole packet: outputs are written once and never re-read by these kernels, so they are
+// stored non-temporally (no L2 allocation competing with the input stream).
+template <typename P>
+__device__ __forceinline__ void store_stream(P *dst, const P &v)
+{
+    constexpr int kWords = sizeof(P) / 4;
+    static_assert(sizeof(P) % 4 == 0, "packet must be dword sized");
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&v);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    if constexpr (kWords % 4 == 0) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < kWords / 4; ++k)
+            __builtin_nontemporal_store(*reinterpret_cast<const u4 *>(src + 4 * k), reinterpret_cast<u4 *>(d) + k);
+    } else if constexpr (kWords % 2 == 0) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < kWords / 2; ++k)
+            __builtin_nontemporal_store(*reinterpret_cast<const u2 *>(src + 2 * k), reinterpret_cast<u2 *>(d) + k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kWords; ++k) __builtin_nontemporal_store(src[k], d + k);
+    }
 }
 
 // Tile geometry -> global flat index of local element ql (see ct_geometry in clair_hip.h).

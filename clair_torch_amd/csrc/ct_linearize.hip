@@ -77,8 +77,8 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
                 so.v[e] = STD == CT_STD_NONE ? 0.0f : sqrtf(gs * gs);
             }
         }
-        *reinterpret_cast<LPacket<float, V> *>(a.lin_out + off) = lo;
-        if constexpr (WRITE_STD) *reinterpret_cast<LPacket<float, V> *>(a.std_out + off) = so;
+        store_stream(reinterpret_cast<LPacket<float, V> *>(a.lin_out + off), lo);
+        if constexpr (WRITE_STD) store_stream(reinterpret_cast<LPacket<float, V> *>(a.std_out + off), so);
     }
 }
 

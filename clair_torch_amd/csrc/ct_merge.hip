@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     const float kk = sqrtf(a.weight_scale * 1.4426950408889634f);
     const float K = -2.0f * a.weight_scale;
 
-    stage_lut<INTERP>(lds, a.lut, C, L);
+    stage_lut<INTERP, true>(lds, a.lut, C, L);
     for (int n = threadIdx.x; n < B; n += blockDim.x) {
         const float it = (float)(1.0 / a.exposure[n]);
         inv_t[n] = it;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
                 lin = ga[e];
                 dfds = 0.0f;
             } else if constexpr (INTERP == CT_INTERP_LINEAR) {
-                dfds = gb[e] - ga[e];
+                dfds = gb[e];  // the staged table holds {g[i], g[i+1] - g[i]}
                 lin = __builtin_fmaf(dfds, frv[e], ga[e]);
                 if constexpr (!kRanged) dfds *= passv[e];
             } else {
@@ -296,18 +296,18 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
             Packet<float, V> o;
 #pragma unroll
             for (int e = 0; e < V; ++e) o.v[e] = (float)mean_o[e];
-            *reinterpret_cast<Packet<float, V> *>(static_cast<float *>(a.mean_out) + q0) = o;
+            store_stream(reinterpret_cast<Packet<float, V> *>(static_cast<float *>(a.mean_out) + q0), o);
         } else {
             Packet<double, V> o;
 #pragma unroll
             for (int e = 0; e < V; ++e) o.v[e] = mean_o[e];
-            *reinterpret_cast<Packet<double, V> *>(static_cast<double *>(a.mean_out) + q0) = o;
+            store_stream(reinterpret_cast<Packet<double, V> *>(static_cast<double *>(a.mean_out) + q0), o);
         }
         if constexpr (kHasStd) {
             Packet<float, V> o;
 #pragma unroll
             for (int e = 0; e < V; ++e) o.v[e] = std_o[e];
-            *reinterpret_cast<Packet<float, V> *>(a.std_out + q0) = o;
+            store_stream(reinterpret_cast<Packet<float, V> *>(a.std_out + q0), o);
         }
     }
 }
@@ -363,12 +363,15 @@ static int dispatch_interp(const MergeArgs &a, int interp, int weight_mode, int 
     return CT_ERR_INVALID_ARGUMENT;
 }
 
-// Elements per thread.  Measured on MI355X (tools/merge_bench.hip, C2 shape, Gaussian + MULTIPLIER std):
-// uint16 V=4 (8-byte packets) 1.18-1.22 ms vs V=8 (16-byte) 1.22-1.26 ms: the kernel is VALU-bound with the
-// uncertainty on, so the smaller register footprint (more resident waves) wins over the wider load.
+// Elements per thread.  Measured on MI355X (tools/merge_bench.hip, C2 shape, Gaussian + MULTIPLIER std, PF = 2):
+// uint16 V=8 (16-byte packets) and V=4 (8-byte) tie within device-to-device noise with the uncertainty on
+// (1.20-1.26 ms vs 1.18-1.30 ms: VALU-bound either way) and V=8 is 7 % faster without it (0.72-0.75 vs 0.78-0.81 ms,
+// HBM-bound), so 16-byte packets are used.  Rejected on measurement (profiles/r01_harness_*.log): float32 block
+// moments (7 % faster, 1.3e-4 parity error), a two-phase variant caching every sample's (a_n, b_n) in registers to
+// drop the float64 FMAs (exact, but 256 VGPRs and 4-byte loads: 2.4 ms), auto-SLP packed float32 (10 % slower).
 template <typename T>
 struct VecWidth {
-    static constexpr int value = sizeof(T) == 1 ? 8 : 4;
+    static constexpr int value = sizeof(T) == 4 ? 4 : 8;
 };
 
 template <typename T>
