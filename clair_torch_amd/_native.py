@@ -18,7 +18,8 @@ MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32 = 1, 2, 4
 ERR_NO_GRADIENT_PATH = -4
 
 EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd",
-           "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd")
+           "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_flatfield_sums",
+           "ct_flatfield_apply")
 
 
 class Geometry(ctypes.Structure):
@@ -77,6 +78,10 @@ def load():
         lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, i32, vp, vp, vp]
         lib.ct_pair_residual_bwd.restype = i32
         lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp]
+    lib.ct_flatfield_sums.restype = i32
+    lib.ct_flatfield_sums.argtypes = [vp, i32, vp, i32, i64, vp, vp]
+    lib.ct_flatfield_apply.restype = i32
+    lib.ct_flatfield_apply.argtypes = [vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i64, vp]
     if lib.ct_abi_version() != 1:
         raise NativeLibraryError(f"{path}: ABI version {lib.ct_abi_version()} != 1; rebuild the library")
     _lib = lib

@@ -1,2 +1,2 @@
 from .collate import custom_collate
-from .stack_dataset import StackDataset, synthetic_exposure_stack
+from .stack_dataset import ArtefactStack, StackDataset, synthetic_exposure_stack

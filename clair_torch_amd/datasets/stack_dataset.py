@@ -56,6 +56,21 @@ class StackDataset(Dataset):
         return i, val, std, {"exposure_time": self.exposure_times[i]}
 
 
+class ArtefactStack:
+    """In-memory stand-in for the reference's FlatFieldArtefactMapDataset (clair_torch/datasets/base.py:175-259):
+    ``get_matching_artefact_images`` returns the collated 4-tuple ``(indices, value (1,C,H,W), std (1,C,H,W) | None,
+    meta)`` of the single calibration image it holds, whatever frame settings are asked for."""
+
+    def __init__(self, value: torch.Tensor, std: Optional[torch.Tensor] = None):
+        if value.ndim != 3:
+            raise ValueError("value must be (C, H, W)")
+        self.value, self.std = value, std
+
+    def get_matching_artefact_images(self, reference_frame_settings_list):
+        std = None if self.std is None else self.std.unsqueeze(0)
+        return torch.tensor([0]), self.value.unsqueeze(0), std, {}
+
+
 def synthetic_exposure_stack(n: int, channels: int, height: int, width: int, bits: int = 16, stops_per_step: float = 0.25,
                              t0: float = 1e-3, seed: int = 1234, device="cpu", row_range=None):
     """Synthetic gamma-2.2 scene of SURVEY 8(d): irradiance E ~ U(0, 2/t_mid) per pixel-channel, exposures

@@ -18,20 +18,24 @@ from ._staging import normalise_transform_list, resolve_device, stage_images, st
 
 def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFModelBase] = None,
                       weight_fn: Optional[Callable] = None, flat_field_dataset=None, gpu_transforms=None,
-                      dark_field_dataset=None, tile: Optional[ops.TileGeometry] = None):
+                      dark_field_dataset=None, tile: Optional[ops.TileGeometry] = None, group=None):
     """Merge the exposure stack served by ``dataloader`` into an HDR image and its standard uncertainty.
 
     Returns ``(mean float64 (C,H,W), std float32 (C,H,W) | None)`` on ``device`` (squeezed like the reference).
     ``weight_fn``: None = unit weights, anything else = Gaussian weights, scale 30 (hdr_merge.py:95).
-    ``tile`` (extension): the rows this process holds of a taller global image (multi-GPU row bands).
+    ``flat_field_dataset``: any object with the reference's ``get_matching_artefact_images`` (e.g.
+    ``clair_torch_amd.datasets.ArtefactStack``); its image must cover the rows this process holds.
+    ``tile`` / ``group`` (extensions): the rows this process holds of a taller global image (multi-GPU row bands) and
+    the process group over which the flat field's spatial sums are all-reduced.
     """
     expect(dataloader, DataLoader, "dataloader")
     expect(device, (str, torch.device), "device")
     expect(icrf_model, ICRFModelBase, "icrf_model", allow_none=True)
     if weight_fn is not None and not callable(weight_fn):
         expect(weight_fn, type(None), "weight_fn")
-    if flat_field_dataset is not None or dark_field_dataset is not None:
-        raise NotImplementedError("flat-field / dark-field corrections are not built yet (SURVEY 8f rows 1 and 4)")
+    if dark_field_dataset is not None:
+        raise NotImplementedError("dark-field correction is not built (SURVEY 8f row 4: parity unpinned, its blur "
+                                  "lives in torchvision which the reference does not vendor)")
     dev = resolve_device(device)
     transforms = normalise_transform_list(gpu_transforms)
     lut = interp = None
@@ -49,10 +53,35 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
         last = pending is None
         images, max_code = stage_images(val_batch, dev, transforms)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
-        if state is None and not last:
+        if state is None and (not last or flat_field_dataset is not None):
             state = ops.MergeState(tuple(images.shape[1:]), dev, with_variance=std_mode != "none")
         result = ops.hdr_merge_batch(images, meta_batch["exposure_time"], lut=lut, interp=interp,
                                      gaussian_weight=weight_fn is not None, std=std, std_mode=std_mode,
-                                     std_value=std_value, max_code=max_code, state=state, finalize=last, tile=tile)
+                                     std_value=std_value, max_code=max_code, state=state,
+                                     finalize=last and flat_field_dataset is None, tile=tile)
+    if flat_field_dataset is not None:
+        return _flat_field_epilogue(state, flat_field_dataset, dataloader.dataset, dev, tile, group)
     mean, std = result
     return mean.squeeze(), (std.squeeze() if std is not None else None)
+
+
+def _flat_field_epilogue(state, flat_field_dataset, main_dataset, dev, tile, group):
+    """hdr_merge.py:131-153 on the device-resident merged state."""
+    import torch.distributed as dist
+    _, flat, flat_std, _ = flat_field_dataset.get_matching_artefact_images([main_dataset.files[0]])
+    if flat_std is None:
+        # the reference dereferences the std unconditionally (hdr_merge.py:134)
+        raise AttributeError("'NoneType' object has no attribute 'to'")
+    if state.var is None:
+        # hdr_merge.py:151: running_variance is None without image uncertainties
+        raise TypeError("unsupported operand type(s) for +: 'NoneType' and 'Tensor'")
+    flat, flat_std = flat.to(dev), flat_std.to(dev)
+    c, h, w = state.mean.shape
+    reduce = global_px = None
+    if tile is not None:
+        global_px = tile.h_global * w
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            reduce = lambda t: dist.all_reduce(t, group=group)  # noqa: E731
+    mean, std = ops.flatfield_correct(state.mean, state.var, flat, flat_std, input_is_variance=True, through_mean=True,
+                                      global_pixels=global_px, reduce=reduce)
+    return mean.squeeze(), std.squeeze()

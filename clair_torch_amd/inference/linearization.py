@@ -23,14 +23,22 @@ def linearize_dataset_generator(dataloader: DataLoader, device, icrf_model: ICRF
     expect(icrf_model, ICRFModelBase, "icrf_model")
     if not dataloader.batch_size == 1:
         raise ValueError("For linearization only batch_size of 1 is allowed.")
-    if flatfield_dataset is not None or dark_field_dataset is not None:
-        raise NotImplementedError("flat-field / dark-field corrections are not built yet (SURVEY 8f rows 1 and 4)")
+    if dark_field_dataset is not None:
+        raise NotImplementedError("dark-field correction is not built (SURVEY 8f row 4: parity unpinned, its blur "
+                                  "lives in torchvision which the reference does not vendor)")
     dev = resolve_device(device)
     transforms = normalise_transform_list(gpu_transforms)
     lut, interp = icrf_model.icrf.detach().to(dev), icrf_model.interp_name
+    flat = flat_std = None
+    if flatfield_dataset is not None:  # linearization.py:48-57
+        _, flat, flat_std, _ = flatfield_dataset.get_matching_artefact_images([dataloader.dataset.files[0]])
+        flat = flat.to(dev)
+        flat_std = flat_std.to(dev) if flat_std is not None else None
     for _, val_batch, std_batch, meta_batch in dataloader:
         images, max_code = stage_images(val_batch, dev, transforms)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
         lin, lin_std = ops.linearize_frames(images, lut, interp, std=std, std_mode=std_mode, std_value=std_value,
                                             max_code=max_code, want_std=True)
+        if flat is not None:  # linearization.py:118-130: mean is a constant, the image term is not rescaled
+            ops.flatfield_correct(lin, lin_std, flat, flat_std, input_is_variance=False, through_mean=False)
         yield lin.squeeze().cpu(), lin_std.squeeze().cpu(), meta_batch

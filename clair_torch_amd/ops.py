@@ -304,3 +304,47 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
         nv.check(rc, "ct_pair_residual_bwd")
     del lut_keep
     return grad
+
+
+# ---- flat-field correction epilogues ----------------------------------------------------------------------------
+def flatfield_correct(value: torch.Tensor, var_or_std: Optional[torch.Tensor], flat: torch.Tensor,
+                      flat_std: Optional[torch.Tensor], *, input_is_variance: bool, through_mean: bool,
+                      global_pixels: Optional[int] = None, reduce=None):
+    """In-place flat-field correction of ``value`` ((C,H,W) float64 merged mean or (F,C,H,W) float32 frames) and of
+    its uncertainty (ct_flatfield_sums + ct_flatfield_apply).  ``through_mean``: the gradient also flows through the
+    flat field's spatial mean (compute_hdr_image) or not (linearize).  ``reduce`` all-reduces the (C,2) sums across
+    ranks holding row bands; ``global_pixels`` is then the pixel count of the whole image plane."""
+    _require_device(value, "value")
+    flat = flat.to(device=value.device, dtype=torch.float32).contiguous()
+    if flat.ndim == 4:
+        flat = flat[0]
+    c, h, w = flat.shape
+    plane = h * w
+    if tuple(value.shape[-3:]) != (c, h, w):
+        raise ValueError(f"flat field {tuple(flat.shape)} does not match the image {tuple(value.shape)}")
+    if not value.is_contiguous():
+        raise ValueError("value must be contiguous")
+    frames = 1 if value.ndim == 3 else value.shape[0]
+    is_f64 = value.dtype == torch.float64
+    if value.dtype not in (torch.float64, torch.float32):
+        raise TypeError("value must be float32 or float64")
+    if flat_std is not None:
+        flat_std = flat_std.to(device=value.device, dtype=torch.float32).contiguous()
+        if flat_std.ndim == 4:
+            flat_std = flat_std[0]
+    dev = value.device
+    sums = torch.zeros((c, 2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_flatfield_sums(_ptr(value) if (through_mean and frames == 1) else None, int(is_f64), _ptr(flat),
+                                         c, plane, _ptr(sums), _stream(dev))
+    nv.check(rc, "ct_flatfield_sums")
+    if reduce is not None:
+        reduce(sums)
+    n_px = float(global_pixels if global_pixels is not None else plane)
+    flat_mean = (sums[:, 0] / n_px).to(torch.float32).contiguous()
+    through = (sums[:, 1] / n_px).contiguous() if through_mean else None
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_flatfield_apply(_ptr(value), int(is_f64), frames, _ptr(var_or_std), int(input_is_variance),
+                                          _ptr(flat), _ptr(flat_std), _ptr(flat_mean), _ptr(through), c, plane, _stream(dev))
+    nv.check(rc, "ct_flatfield_apply")
+    return value, var_or_std

@@ -176,6 +176,26 @@ int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float max_code, i
                          const int32_t *partner_pair_dev, const ct_pair_params *params, const double *coef_dev,
                          double *lut_grad_dev, void *stream);
 
+/*
+ * Flat-field correction epilogues (clair_torch/inference/hdr_merge.py:131-153, linearization.py:48-57,118-130;
+ * flat_field_mean / flatfield_correction, clair_torch/common/general_functions.py:182-238, whole-image ROI as both
+ * call sites pass mid_area_side_fraction = 1.0).
+ *
+ * ct_flatfield_sums: sums_dev (C, 2) float64 += [sum flat, sum value / (flat + 1e-6)] over a (C, plane) band
+ *   (value_dev may be NULL: only the first sum).  Additive over row bands: ranks all-reduce, then divide by the global
+ *   pixel count to get M_c (float32) and the "through the mean" gradient term.
+ * ct_flatfield_apply: value (F, C, plane) float64 or float32, in place: value / (flat + 1e-6) * M_c;
+ *   var_or_std_dev (F, C, plane) float32 in place (or NULL): on entry the variance (input_is_variance != 0, merge)
+ *   or the std (linearize) of the image term, on exit sqrt(var + (grad * flat_std)^2) with
+ *   grad = -value * M_c / (flat + 1e-6)^2 + through_mean_dev[c]  (through_mean_dev NULL = 0, flat_std_dev NULL = no term).
+ */
+int ct_flatfield_sums(const void *value_dev, int32_t value_is_f64, const float *flat_dev, int32_t channels,
+                      int64_t plane, double *sums_dev, void *stream);
+int ct_flatfield_apply(void *value_dev, int32_t value_is_f64, int64_t n_frames, float *var_or_std_dev,
+                       int32_t input_is_variance, const float *flat_dev, const float *flat_std_dev,
+                       const float *flat_mean_dev, const double *through_mean_dev, int32_t channels, int64_t plane,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

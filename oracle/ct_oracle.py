@@ -38,6 +38,8 @@ def lib():
         L.cto_hdr_merge_batch.restype = i32
         L.cto_linearize_std.argtypes = [vp, vp, i64, i32, i64, i64, vp, i32, i32, vp, vp, i64, i64]
         L.cto_linearize_std.restype = i32
+        L.cto_flatfield_merge.argtypes = [vp, vp, vp, vp, i32, i64]
+        L.cto_flatfield_linearize.argtypes = [vp, vp, vp, vp, i64, i32, i64]
         L.cto_pair_sums.argtypes = [vp, vp, vp, i64, i32, i64, i64, vp, vp, vp, i64, f32, f32, i32, i32, vp]
         _lib = L
     return _lib
@@ -164,3 +166,24 @@ def spatial_stats(sums, have_err):
     std = np.sqrt(np.maximum(var, 0.0))
     err = s3 / np.maximum(s4, 1e-8) if have_err else None
     return mean, std, err
+
+
+def flatfield_merge(mean, std, flat, flat_std):
+    """Flat-field epilogue of compute_hdr_image on a merged (mean f64, std f32): returns corrected (mean, std)."""
+    c = mean.shape[0]
+    p = int(np.prod(mean.shape[1:]))
+    m = np.ascontiguousarray(mean, dtype=np.float64).copy()
+    var = (np.ascontiguousarray(std, dtype=np.float32) ** 2).astype(np.float32)
+    flat, flat_std = _f32(flat), _f32(flat_std)
+    lib().cto_flatfield_merge(_p(m), _p(var), _p(flat), _p(flat_std), c, p)
+    return m, np.sqrt(var)
+
+
+def flatfield_linearize(lin, std, flat, flat_std):
+    """Flat-field epilogue of linearize_dataset_generator for (F,C,H,W) frames: corrected (lin, std) float32."""
+    f, c = lin.shape[:2]
+    p = int(np.prod(lin.shape[2:]))
+    lo, so = _f32(lin).copy(), _f32(std).copy()
+    flat, flat_std = _f32(flat), _f32(flat_std)
+    lib().cto_flatfield_linearize(_p(lo), _p(so), _p(flat), _p(flat_std), f, c, p)
+    return lo, so

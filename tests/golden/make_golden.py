@@ -391,9 +391,69 @@ def gen_helpers(out):
     out["ff_corrected"] = flatfield_correction(im, ff, fm).numpy()
 
 
+class FakeFlatField:
+    """Duck-typed FlatFieldArtefactMapDataset: returns one collated (1,C,H,W) value (and std) image."""
+
+    def __init__(self, val, std):
+        self.val, self.std = val, std
+
+    def get_matching_artefact_images(self, _frame_settings_list):
+        std = None if self.std is None else self.std.unsqueeze(0)
+        return torch.tensor([0]), self.val.unsqueeze(0), std, {"exposure_time": torch.tensor([1.0], dtype=torch.float64)}
+
+
+def gen_flatfield(out):
+    """Flat-field correction epilogues of compute_hdr_image (hdr_merge.py:131-153) and
+    linearize_dataset_generator (linearization.py:48-57,118-130)."""
+    gen = torch.Generator().manual_seed(606)
+    lut = lut_rows((2.2, 2.4, 2.6))
+    out["ff_lut"] = lut.numpy()
+    n, c, h, w = 6, 3, 12, 10
+    exposures = [0.001 * 2.0 ** k for k in range(n)]
+    out["ff_exposures"] = np.asarray(exposures)
+    codes = synthetic_codes(gen, n, c, h, w, 65535, exposures)
+    out["ff_codes"] = codes.numpy().astype(np.uint16)
+    vals = [normalize_tensor(codes[i].float(), max_val=65535, min_val=0) for i in range(n)]
+    flat = 0.6 + 0.4 * torch.rand((c, h, w), generator=gen)
+    flat_std = 0.002 + 0.01 * torch.rand((c, h, w), generator=gen)
+    out["ff_flat"], out["ff_flat_std"] = flat.numpy(), flat_std.numpy()
+    for fsname, fstd in (("ffstd", flat_std), ("noffstd", None)):
+        for pname, partition in (("6", [6]), ("33", [3, 3])):
+            ds = MemoryStack([v.clone() for v in vals], make_stds(vals, "multiplier", gen), exposures)
+            model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=InterpMode.LINEAR)
+            ff = FakeFlatField(flat.clone(), None if fstd is None else fstd.clone())
+            if fstd is None:
+                # hdr_merge.py:134 calls flatfield_std.to(...) unconditionally: a flat field without std crashes
+                try:
+                    compute_hdr_image(partition_loader(ds, partition), "cpu", model,
+                                      weight_fn=ref_losses.gaussian_value_weights, flat_field_dataset=ff)
+                    out["ffmerge_noffstd_raises"] = np.asarray(0)
+                except AttributeError:
+                    out["ffmerge_noffstd_raises"] = np.asarray(1)
+                continue
+            mean, std = compute_hdr_image(partition_loader(ds, partition), "cpu", model,
+                                          weight_fn=ref_losses.gaussian_value_weights, flat_field_dataset=ff)
+            out[f"ffmerge_{fsname}_{pname}_mean"] = mean.detach().numpy()
+            out[f"ffmerge_{fsname}_{pname}_std"] = std.detach().numpy()
+        # linearize, 3 frames
+        for sname in ("none", "multiplier"):
+            stds = make_stds(vals[:3], sname, gen)
+            ds = MemoryStack([v.clone() for v in vals[:3]], stds, exposures[:3])
+            model = ICRFModelDirect(icrf=lut.clone(), interpolation_mode=InterpMode.LINEAR)
+            loader = DataLoader(ds, batch_size=1, shuffle=False, collate_fn=custom_collate)
+            ff = FakeFlatField(flat.clone(), None if fstd is None else fstd.clone())
+            lins, sds = [], []
+            for lin, sd, _ in linearize_dataset_generator(loader, "cpu", model, flatfield_dataset=ff):
+                lins.append(lin.numpy())
+                sds.append(sd.numpy())
+            out[f"fflin_{fsname}_{sname}_val"] = np.stack(lins)
+            out[f"fflin_{fsname}_{sname}_std"] = np.stack(sds)
+
+
 def main():
     for name, fn in (("model_forward", gen_model_forward), ("merge", gen_merge), ("merge_c1", gen_merge_c1),
-                     ("linearize", gen_linearize), ("training", gen_training), ("helpers", gen_helpers)):
+                     ("linearize", gen_linearize), ("training", gen_training), ("helpers", gen_helpers),
+                     ("flatfield", gen_flatfield)):
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

@@ -225,3 +225,24 @@ def test_gaussian_weights_and_helpers():
                                        torch.from_numpy(g["wms_mask"]))
     assert_parity(m.numpy(), g["wms_mean"], rtol=1e-12, norm_tol=1e-12)
     assert_parity(s.numpy(), g["wms_std"], rtol=1e-12, norm_tol=1e-12)
+
+
+def test_flatfield_epilogues_vs_golden():
+    """Flat-field correction + its variance term for merge and linearize."""
+    g = golden("flatfield")
+    x = oc.normalize_codes(g["ff_codes"])
+    sd = x * np.float32(0.05)
+    t, lut, flat, fstd = g["ff_exposures"], g["ff_lut"], g["ff_flat"], g["ff_flat_std"]
+    assert int(g["ffmerge_noffstd_raises"]) == 1      # hdr_merge.py:134 dereferences a None std
+    for pname, part in (("6", [6]), ("33", [3, 3])):
+        mean, std = oc.hdr_merge(x, sd, t, lut, "linear", True, part)
+        # note: the merged variance is carried in float32; going through std = sqrt(var) costs one rounding
+        mc, sc = oc.flatfield_merge(mean, std, flat, fstd)
+        assert_parity(mc, g[f"ffmerge_ffstd_{pname}_mean"], rtol=1e-6, norm_tol=1e-6, what="ff mean")
+        assert_parity(sc, g[f"ffmerge_ffstd_{pname}_std"], norm_tol=1e-5, elem_tol=2e-5, what="ff std")
+    for fsname, fs in (("ffstd", fstd), ("noffstd", None)):
+        for sname in ("none", "multiplier"):
+            lin, so = oc.linearize_std(x[:3], None if sname == "none" else sd[:3], lut, "linear")
+            lc, sc = oc.flatfield_linearize(lin, so, flat, fs)
+            assert_parity(lc, g[f"fflin_{fsname}_{sname}_val"], rtol=2e-7, norm_tol=1e-7, what="ff lin")
+            assert_parity(sc, g[f"fflin_{fsname}_{sname}_std"], rtol=1e-6, norm_tol=1e-6, what="ff lin std")
