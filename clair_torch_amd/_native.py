@@ -77,7 +77,7 @@ def load():
         lib.ct_pair_residual_fwd.restype = i32
         lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, i32, vp, vp, vp]
         lib.ct_pair_residual_bwd.restype = i32
-        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp]
+        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp, vp]
     lib.ct_flatfield_sums.restype = i32
     lib.ct_flatfield_sums.argtypes = [vp, i32, vp, i32, i64, vp, vp]
     lib.ct_flatfield_apply.restype = i32

@@ -37,6 +37,7 @@ struct PairArgs {
     // backward only
     const int32_t *part_off, *part_sample, *part_pair;  // CSR partner lists per sample
     const double *coef;                                 // (P, C)
+    const double *smean;                                // (P, C) spatial means (uncertainty-weighted backward)
     double *lut_grad;                                   // (C, L) float64, +=
     int64_t image_stride;
     TileMap tile;
@@ -61,7 +62,7 @@ __device__ __forceinline__ float load_pixel(const void *base, int64_t idx, NormC
 //   aux[n*pitch + px] = LUT coordinate s (backward) or linearized std |f'(x) sigma| (forward, STD != none)
 template <typename T, int INTERP, int STD, bool WANT_COORD>
 __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_lds, float2 *val, float *aux, int c,
-                                           uint32_t pix0, int npix)
+                                           uint32_t pix0, int npix, float *aux2 = nullptr)
 {
     constexpr bool kRanged = sizeof(T) != 4;
     constexpr int kEntry = lut_entry_bytes(INTERP);
@@ -71,7 +72,7 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
     for (int k = threadIdx.x; k < total; k += blockDim.x) {
         const int n = k / a.tp, px = k - n * a.tp;
         float2 v = make_float2(0.0f, -1.0f);
-        float ax = 0.0f;
+        float ax = 0.0f, ax2 = 0.0f;
         if (px < npix) {
             const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + px;
             const int64_t off = (int64_t)n * a.image_stride + ql;
@@ -86,23 +87,29 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
             const float gw = __builtin_amdgcn_exp2f((d * d) * a.neg_scale_log2e);
             const bool valid = x >= a.lower && x <= a.upper;
             v = make_float2(lin, valid ? gw : -gw);
-            if constexpr (WANT_COORD) {
-                ax = fminf(fmaxf(x * top, 0.0f), top);
-            } else if constexpr (STD != CT_STD_NONE) {
+            float lsd = 0.0f;
+            if constexpr (STD != CT_STD_NONE) {
                 float sigma = a.std_value;
                 if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;
                 if constexpr (STD == CT_STD_EXPLICIT) sigma = a.std_stack[off];
-                ax = fabsf(dfdx * sigma);  // icrf_training.py:117-126: |grads * stds|
+                lsd = fabsf(dfdx * sigma);  // icrf_training.py:117-126: |grads * stds|
+            }
+            if constexpr (WANT_COORD) {
+                ax = fminf(fmaxf(x * top, 0.0f), top);
+                ax2 = lsd;
+            } else {
+                ax = lsd;
             }
         }
         val[n * a.row_pitch + px] = v;
         if constexpr (WANT_COORD || STD != CT_STD_NONE) aux[n * a.row_pitch + px] = ax;
+        if constexpr (WANT_COORD && STD != CT_STD_NONE) aux2[n * a.row_pitch + px] = ax2;
     }
 }
 
 // ---- forward -------------------------------------------------------------------------------------
 // LEVEL 0: sums 0,1 (training loss).  LEVEL 1: all five sums (measure_linearity: std, error, count).
-template <typename T, int INTERP, int STD, int PPT, int LEVEL>
+template <typename T, int INTERP, int STD, int PPT, int LEVEL, bool REL>
 __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
 {
     extern __shared__ __align__(16) char lds[];
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
             for (int k = 0; k < NS; ++k) f[k] = 0.0f;
             const float2 *vi = val + bi[s], *vj = val + bj[s];
             const float *xi = aux + bi[s], *xj = aux + bj[s];
-#pragma unroll 4
+#pragma unroll 8
             for (int px = 0; px < npix; ++px) {
                 const float2 A = vi[px], Bv = vj[px];
                 // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
@@ -167,14 +174,14 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
                 float diff = __builtin_fmaf(-Bv.x, rlo[s], d1);
                 const float es = e + 1e-6f;
                 const float inv_es = __builtin_amdgcn_rcpf(es);
-                if (a.use_relative) diff *= inv_es;
+                if constexpr (REL) diff *= inv_es;
                 const float v = fabsf(diff);
                 const bool m = fminf(A.y, Bv.y) > 0.0f;  // both samples inside [lower, upper]
                 float wt = fabsf(A.y) + fabsf(Bv.y);      // Gaussian pair weight (losses.py:231-234)
                 float err = 0.0f;
                 if constexpr (STD != CT_STD_NONE) {
                     const float si = xi[px], sj = xj[px];
-                    if (a.use_relative) {  // losses.py:52-59
+                    if constexpr (REL) {  // losses.py:52-59
                         const float ijs = fmaxf(Bv.x, 1e-6f);
                         const float t1 = si * inv_es;
                         const float t2 = (A.x * sj) * inv_es * __builtin_amdgcn_rcpf(ijs);
@@ -213,8 +220,23 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
 // ---- backward ------------------------------------------------------------------------------------
 // coef[p][c] = dL/d(spatial mean_pc) / max(sum w m, 1e-8): the weights do not depend on the LUT when
 // use_uncertainty_weighting is off, so d mean / d I = w m / den * d v / d I.
-template <typename T, int INTERP>
-__global__ __launch_bounds__(kBlock) void pair_bwd_kernel(const PairArgs a)
+// One partner-list entry, resolved once per workgroup into LDS so the inner loop has no dependent scalar loads:
+// partner sample's LDS row, which side of the pair this sample is on, the ratio split in two floats, and the
+// upstream coefficient of that pair for this workgroup's channel.
+struct PartnerEntry {
+    int row;    // partner sample * row_pitch, bit 31 set when the OWN sample is the pair's second image (j)
+    float rhi, rlo, cf;
+    float sm;   // spatial mean of the pair (only read by the uncertainty-weighted backward)
+};
+
+// 512 threads (8 waves) per workgroup: at N = 64 the staged tile + partner entries take ~90 KB of LDS, so only one
+// workgroup fits a CU; eight waves keep two per SIMD to cover the LDS latency of the partner loop.
+constexpr int kBwdBlock = 512;
+
+// STD != CT_STD_NONE selects the uncertainty-weighted loss (weights w = 1/(err + 1e-6) + gauss, losses.py:93-100),
+// whose weights depend on the LUT through err when the loss is relative:  d mean = sum m [w dv + (v - mean) dw] / D.
+template <typename T, int INTERP, bool REL, int STD>
+__global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
 {
     extern __shared__ __align__(16) char lds[];
     constexpr int kEntry = lut_entry_bytes(INTERP);
@@ -222,23 +244,39 @@ __global__ __launch_bounds__(kBlock) void pair_bwd_kernel(const PairArgs a)
     const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
     double *hist64 = reinterpret_cast<double *>(lds + lut_bytes);
     float *hist32 = reinterpret_cast<float *>(hist64 + C * L);
-    float2 *val = reinterpret_cast<float2 *>(hist32 + ((C * L + 3) & ~3));
+    PartnerEntry *ent = reinterpret_cast<PartnerEntry *>(hist32 + ((C * L + 3) & ~3));
+    const int n_ent = 2 * a.n_pairs;
+    float2 *val = reinterpret_cast<float2 *>(ent + n_ent);
     float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
+    float *lsdv = aux + (size_t)N * a.row_pitch;  // linearized std per sample (STD != none only)
+    constexpr bool kUnc = STD != CT_STD_NONE;
+    const int c = blockIdx.x % C;
     stage_lut<INTERP>(lds, a.lut, C, L);
     for (int k = threadIdx.x; k < C * L; k += blockDim.x) {
         hist64[k] = 0.0;
         hist32[k] = 0.0f;
     }
-    const int c = blockIdx.x % C;
+    for (int e = threadIdx.x; e < n_ent; e += blockDim.x) {
+        const int code = a.part_pair[e];
+        const bool own_is_i = code >= 0;
+        const int p = own_is_i ? code : ~code;
+        const double r = a.ratio[p];
+        PartnerEntry pe;
+        pe.row = (a.part_sample[e] * a.row_pitch) | (own_is_i ? 0 : (int)0x80000000);
+        pe.rhi = (float)r;
+        pe.rlo = (float)(r - (double)pe.rhi);
+        pe.cf = (float)a.coef[(int64_t)p * C + c];
+        pe.sm = kUnc ? (float)a.smean[(int64_t)p * C + c] : 0.0f;
+        ent[e] = pe;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
-    const float top = (float)(L - 1);
     for (uint32_t t = blockIdx.x / C; t < tiles; t += gstep) {
         const uint32_t pix0 = t * a.tp;
         const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
         __syncthreads();
-        stage_tile<T, INTERP, CT_STD_NONE, true>(a, lds, val, aux, c, pix0, npix);
+        stage_tile<T, INTERP, STD, true>(a, lds, val, aux, c, pix0, npix, lsdv);
         __syncthreads();
         for (int px = lane; px < a.tp; px += 64) {
             const bool inb = px < npix;
@@ -248,33 +286,53 @@ __global__ __launch_bounds__(kBlock) void pair_bwd_kernel(const PairArgs a)
             float *hrow = hist32 + lut_row<INTERP>(qg, ch, C) * L;
             for (int n = wave; n < N; n += nwaves) {
                 const float2 own = val[n * a.row_pitch + px];
+                const float own_sd = kUnc ? lsdv[n * a.row_pitch + px] : 0.0f;
                 float G = 0.0f;
                 const int e0 = a.part_off[n], e1 = a.part_off[n + 1];
+#pragma unroll 4
                 for (int e = e0; e < e1; ++e) {
-                    const int m = a.part_sample[e];
-                    const int code = a.part_pair[e];
-                    const bool own_is_i = code >= 0;
-                    const int p = own_is_i ? code : ~code;
-                    const double r = a.ratio[p];
-                    const float rhi = (float)r, rlo = (float)(r - (double)rhi);
-                    const float cf = (float)a.coef[(int64_t)p * C + c];
-                    const float2 oth = val[m * a.row_pitch + px];
+                    const PartnerEntry pe = ent[e];
+                    const bool own_is_i = pe.row >= 0;
+                    const float2 oth = val[(pe.row & 0x7fffffff) + px];
                     const float Ii = own_is_i ? own.x : oth.x, Ij = own_is_i ? oth.x : own.x;
-                    const float ev = Ij * rhi;
-                    const float d1 = __builtin_fmaf(-Ij, rhi, Ii);
-                    const float diff = __builtin_fmaf(-Ij, rlo, d1);
+                    const float ev = Ij * pe.rhi;
+                    const float d1 = __builtin_fmaf(-Ij, pe.rhi, Ii);
+                    const float diff = __builtin_fmaf(-Ij, pe.rlo, d1);
                     const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
                     const bool mk = fminf(own.y, oth.y) > 0.0f;
-                    const float wm = mk ? fabsf(own.y) + fabsf(oth.y) : 0.0f;
-                    float dv;
-                    if (a.use_relative) {
+                    float wt = fabsf(own.y) + fabsf(oth.y);
+                    float dv, extra = 0.0f;  // extra = (v - mean) dw/dI_own
+                    if constexpr (REL) {
                         const float inv_es = __builtin_amdgcn_rcpf(ev + 1e-6f);
                         // v = |(I_i - e)/(e + eps)|: dv/dI_i = sgn/(e+eps); dv/dI_j = -sgn r (I_i + eps)/(e+eps)^2
-                        dv = own_is_i ? sgn * inv_es : -sgn * rhi * (Ii + 1e-6f) * inv_es * inv_es;
+                        dv = own_is_i ? sgn * inv_es : -sgn * pe.rhi * (Ii + 1e-6f) * inv_es * inv_es;
+                        if constexpr (kUnc) {
+                            const float oth_sd = lsdv[(pe.row & 0x7fffffff) + px];
+                            const float si = own_is_i ? own_sd : oth_sd, sj = own_is_i ? oth_sd : own_sd;
+                            const float inv_ijs = __builtin_amdgcn_rcpf(fmaxf(Ij, 1e-6f));
+                            const float t1 = si * inv_es, t2 = (Ii * sj) * inv_es * inv_ijs;  // losses.py:55-57
+                            const float err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
+                            const float uw = __builtin_amdgcn_rcpf(err + 1e-6f);
+                            wt += uw;
+                            float derr;
+                            if (own_is_i)  // d err / d I_i: only t2 depends on I_i
+                                derr = t2 * (sj * inv_es * inv_ijs);
+                            else  // d err / d I_j: both terms through (e + eps), t2 also through clamp(I_j, eps)
+                                derr = -(t1 * t1 * pe.rhi * inv_es +
+                                         t2 * t2 * (pe.rhi * inv_es + (Ij >= 1e-6f ? inv_ijs : 0.0f)));
+                            derr *= __builtin_amdgcn_rcpf(err);
+                            extra = (fabsf(diff * inv_es) - pe.sm) * (-uw * uw * derr);
+                        }
                     } else {
-                        dv = own_is_i ? sgn : -sgn * rhi;
+                        dv = own_is_i ? sgn : -sgn * pe.rhi;
+                        if constexpr (kUnc) {  // losses.py:61: the error does not depend on the LUT
+                            const float oth_sd = lsdv[(pe.row & 0x7fffffff) + px];
+                            const float si = own_is_i ? own_sd : oth_sd, sj = own_is_i ? oth_sd : own_sd;
+                            const float rs = pe.rhi * sj;
+                            wt += __builtin_amdgcn_rcpf(sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
+                        }
                     }
-                    G = __builtin_fmaf(cf * wm, dv, G);
+                    G = __builtin_fmaf(mk ? pe.cf : 0.0f, __builtin_fmaf(wt, dv, extra), G);
                 }
                 if (inb && G != 0.0f) {
                     const float s = aux[n * a.row_pitch + px];
@@ -311,7 +369,6 @@ __global__ __launch_bounds__(kBlock) void pair_bwd_kernel(const PairArgs a)
                 hist32[k] = 0.0f;
             }
         }
-        (void)top;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < C * L; k += blockDim.x)
@@ -333,10 +390,17 @@ static int pick_tile(int n_images, size_t fixed_bytes, int bytes_per_entry, int 
 template <typename T, int INTERP, int STD, int PPT>
 static int fwd_launch_level(const PairArgs &a, size_t lds, int grid, int level, hipStream_t s)
 {
-    if (level == 0)
-        hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 0>), dim3(grid), dim3(kBlock), lds, s, a);
-    else
-        hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 1>), dim3(grid), dim3(kBlock), lds, s, a);
+    if (level == 0) {
+        if (a.use_relative)
+            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 0, true>), dim3(grid), dim3(kBlock), lds, s, a);
+        else
+            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 0, false>), dim3(grid), dim3(kBlock), lds, s, a);
+    } else {
+        if (a.use_relative)
+            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 1, true>), dim3(grid), dim3(kBlock), lds, s, a);
+        else
+            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 1, false>), dim3(grid), dim3(kBlock), lds, s, a);
+    }
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
@@ -345,13 +409,14 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
 {
     const size_t lut_bytes = INTERP == CT_INTERP_NONE ? 0 : (((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15);
     const int entry = STD == CT_STD_NONE ? 8 : 12;
-    const int tp = pick_tile(a.n_images, lut_bytes, entry, 128);
+    // 64-pixel tiles: ~40 KB of LDS at N = 64 -> four workgroups (16 waves) per CU hide the LDS latency of phase 2
+    const int tp = pick_tile(a.n_images, lut_bytes, entry, 64);
     if (tp == 0) return CT_ERR_TOO_LARGE;
     a.tp = tp;
     a.row_pitch = tp + 1;
     const size_t lds = lut_bytes + (size_t)a.n_images * a.row_pitch * entry;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
-    int per_chan = (int)std::min<uint32_t>(tiles, 512u / (uint32_t)a.channels + 1);
+    int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
     const int grid = per_chan * a.channels;
     // pairs are walked in chunks of 4 * 256 per launch
     for (int begin = 0; begin < a.n_pairs; begin += 4 * kBlock) {
@@ -393,31 +458,47 @@ static int fwd_dispatch(const PairArgs &a, int interp, int std_mode, int level, 
     return CT_ERR_INVALID_ARGUMENT;
 }
 
-template <typename T, int INTERP>
+template <typename T, int INTERP, int STD>
 static int bwd_launch_pairs(PairArgs a, hipStream_t s)
 {
     const size_t lut_bytes = ((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15;
     const size_t cl = (size_t)a.channels * a.n_points;
-    const size_t fixed = lut_bytes + cl * 8 + ((cl + 3) & ~(size_t)3) * 4;
-    const int tp = pick_tile(a.n_images, fixed, 12, 64);
+    const size_t fixed = lut_bytes + cl * 8 + ((cl + 3) & ~(size_t)3) * 4 + (size_t)2 * a.n_pairs * sizeof(PartnerEntry);
+    const int per_sample = STD == CT_STD_NONE ? 12 : 16;
+    const int tp = pick_tile(a.n_images, fixed, per_sample, 64);
     if (tp == 0) return CT_ERR_TOO_LARGE;
     a.tp = tp;
     a.row_pitch = tp + 1;
-    const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * 12;
+    const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
     int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
     const int grid = per_chan * a.channels;
-    hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP>), dim3(grid), dim3(kBlock), lds, s, a);
+    if (a.use_relative)
+        hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, true, STD>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+    else
+        hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, false, STD>), dim3(grid), dim3(kBwdBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
+template <typename T, int INTERP>
+static int bwd_dispatch_std(const PairArgs &a, int std_mode, hipStream_t s)
+{
+    switch (std_mode) {
+        case CT_STD_NONE: return bwd_launch_pairs<T, INTERP, CT_STD_NONE>(a, s);
+        case CT_STD_CONSTANT: return bwd_launch_pairs<T, INTERP, CT_STD_CONSTANT>(a, s);
+        case CT_STD_MULTIPLIER: return bwd_launch_pairs<T, INTERP, CT_STD_MULTIPLIER>(a, s);
+        case CT_STD_EXPLICIT: return bwd_launch_pairs<T, INTERP, CT_STD_EXPLICIT>(a, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
 template <typename T>
-static int bwd_dispatch(const PairArgs &a, int interp, hipStream_t s)
+static int bwd_dispatch(const PairArgs &a, int interp, int std_mode, hipStream_t s)
 {
     switch (interp) {
-        case CT_INTERP_LOOKUP: return bwd_launch_pairs<T, CT_INTERP_LOOKUP>(a, s);
-        case CT_INTERP_LINEAR: return bwd_launch_pairs<T, CT_INTERP_LINEAR>(a, s);
-        case CT_INTERP_CATMULL: return bwd_launch_pairs<T, CT_INTERP_CATMULL>(a, s);
+        case CT_INTERP_LOOKUP: return bwd_dispatch_std<T, CT_INTERP_LOOKUP>(a, std_mode, s);
+        case CT_INTERP_LINEAR: return bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, s);
+        case CT_INTERP_CATMULL: return bwd_dispatch_std<T, CT_INTERP_CATMULL>(a, std_mode, s);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
@@ -494,42 +575,44 @@ extern "C" int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float 
 }
 
 extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
-                                    const ct_geometry *geom, const ct_icrf *icrf, const double *ratio_dev,
-                                    int32_t n_pairs, const int32_t *partner_offsets_dev,
+                                    const ct_geometry *geom, const float *std_dev, const ct_icrf *icrf,
+                                    const double *ratio_dev, int32_t n_pairs, const int32_t *partner_offsets_dev,
                                     const int32_t *partner_sample_dev, const int32_t *partner_pair_dev,
-                                    const ct_pair_params *params, const double *coef_dev, double *lut_grad_dev,
-                                    void *stream)
+                                    const ct_pair_params *params, const double *coef_dev, const double *smean_dev,
+                                    double *lut_grad_dev, void *stream)
 {
     using namespace ct;
+    if (!params) return CT_ERR_INVALID_ARGUMENT;
+    // uncertainties only matter to the backward through the weights: without uncertainty weighting they are ignored
+    ct_pair_params prm = *params;
+    if (!prm.use_uncertainty_weighting) prm.std_mode = CT_STD_NONE;
     PairArgs a{};
-    int rc = fill_common(a, stack_dev, n_images, geom, nullptr, icrf, params, n_pairs);
-    if (rc == CT_ERR_INVALID_ARGUMENT && params && params->std_mode == CT_STD_EXPLICIT) {
-        // the backward never reads the std stack (weights are LUT-independent without uncertainty weighting)
-        ct_pair_params p2 = *params;
-        p2.std_mode = CT_STD_NONE;
-        rc = fill_common(a, stack_dev, n_images, geom, nullptr, icrf, &p2, n_pairs);
-    }
+    int rc = fill_common(a, stack_dev, n_images, geom, std_dev, icrf, &prm, n_pairs);
     if (rc != CT_OK) return rc;
     if (n_pairs == 0) return CT_OK;
     if (!ratio_dev || !partner_offsets_dev || !partner_sample_dev || !partner_pair_dev || !coef_dev || !lut_grad_dev)
         return CT_ERR_INVALID_ARGUMENT;
     if (icrf->interp == CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
-    if (params->use_uncertainty_weighting && params->std_mode != CT_STD_NONE) return CT_ERR_UNSUPPORTED;
+    if (prm.std_mode != CT_STD_NONE) {
+        if (!smean_dev) return CT_ERR_INVALID_ARGUMENT;
+        if (icrf->interp == CT_INTERP_LOOKUP) return CT_ERR_NO_GRADIENT_PATH;
+    }
     a.ratio = ratio_dev;
     a.part_off = partner_offsets_dev;
     a.part_sample = partner_sample_dev;
     a.part_pair = partner_pair_dev;
     a.coef = coef_dev;
+    a.smean = smean_dev;
     a.lut_grad = lut_grad_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
         case CT_DTYPE_U8:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
-            return bwd_dispatch<uint8_t>(a, icrf->interp, s);
+            return bwd_dispatch<uint8_t>(a, icrf->interp, prm.std_mode, s);
         case CT_DTYPE_U16:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
-            return bwd_dispatch<uint16_t>(a, icrf->interp, s);
-        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, s);
+            return bwd_dispatch<uint16_t>(a, icrf->interp, prm.std_mode, s);
+        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, prm.std_mode, s);
     }
     return CT_ERR_UNSUPPORTED;
 }

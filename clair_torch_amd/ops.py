@@ -281,16 +281,31 @@ def pair_residual_sums(stack: torch.Tensor, pairs: PairList, *, lut: Optional[to
 
 def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Tensor, *, lut: torch.Tensor, interp: str,
                            lower: float, upper: float, use_relative: bool, max_code: Optional[float] = None,
-                           tile: Optional[TileGeometry] = None):
-    """ct_pair_residual_bwd -> (C, L) float64 gradient of sum_pc coef_pc * (sum v w m)_pc with respect to the LUT."""
+                           tile: Optional[TileGeometry] = None, use_unc_weight: bool = False,
+                           std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
+                           smean: Optional[torch.Tensor] = None):
+    """ct_pair_residual_bwd -> (C, L) float64 LUT gradient of sum_pc coef_pc * D_pc * mean_pc (coef = dL/dmean / D).
+    With ``use_unc_weight`` and uncertainties the weights depend on the LUT and ``smean`` (P,C) is required."""
     _check_stack(stack)
     n, c, _, _ = stack.shape
     dev = stack.device
+    if std is not None:
+        std_mode = "explicit"
+        std = std.to(device=dev, dtype=torch.float32).contiguous()
+        stack = stack.contiguous()
+    if not use_unc_weight:
+        std, std_mode = None, "none"
     if stack.dtype != torch.float32 and max_code is None:
         max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
     icrf, lut_keep = _icrf_struct(lut, interp, c)
     geom = _geometry(stack, tile)
-    prm = _pair_params(lower, upper, use_relative, False, "none", 0.0)
+    prm = _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value)
+    if std_mode != "none":
+        if smean is None:
+            raise ValueError("the uncertainty-weighted backward needs the forward's spatial means")
+        smean = smean.to(device=dev, dtype=torch.float64).contiguous()
+    else:
+        smean = None
     coef = coef.to(device=dev, dtype=torch.float64).contiguous()
     if coef.shape != (pairs.n_pairs, c):
         raise ValueError(f"coef must be (P={pairs.n_pairs}, C={c}), got {tuple(coef.shape)}")
@@ -298,9 +313,10 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
     if pairs.n_pairs:
         with torch.cuda.device(dev):
             rc = nv.load().ct_pair_residual_bwd(_ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), n,
-                                                ctypes.byref(geom), ctypes.byref(icrf), _ptr(pairs.ratio), pairs.n_pairs,
-                                                _ptr(pairs.part_off), _ptr(pairs.part_sample), _ptr(pairs.part_pair),
-                                                ctypes.byref(prm), _ptr(coef), _ptr(grad), _stream(dev))
+                                                ctypes.byref(geom), _ptr(std), ctypes.byref(icrf), _ptr(pairs.ratio),
+                                                pairs.n_pairs, _ptr(pairs.part_off), _ptr(pairs.part_sample),
+                                                _ptr(pairs.part_pair), ctypes.byref(prm), _ptr(coef), _ptr(smean),
+                                                _ptr(grad), _stream(dev))
         nv.check(rc, "ct_pair_residual_bwd")
     del lut_keep
     return grad

@@ -65,14 +65,11 @@ class _LinearityTerm(torch.autograd.Function):
     def backward(ctx, grad_lin, _grad_spatial):
         lut, spatial, den, lin = ctx.saved_tensors
         kw = ctx.kw
-        if kw["use_unc_weight"] and kw["std_mode"] != "none":
-            raise NotImplementedError(
-                "backward of the linearity loss with use_uncertainty_weighting=True and uncertainty images is not "
-                "built yet: the weights 1/(err+1e-6) then depend on the ICRF (clair_torch/training/losses.py:52-59,96)")
         coef = (grad_lin.to(torch.float64) / lin).unsqueeze(0) * spatial / den
         grad = ops.pair_residual_lut_grad(ctx.stack, ctx.pairs, coef, lut=lut, interp=kw["interp"], lower=kw["lower"],
                                           upper=kw["upper"], use_relative=kw["use_relative"], max_code=kw["max_code"],
-                                          tile=kw["tile"])
+                                          tile=kw["tile"], use_unc_weight=kw["use_unc_weight"], std=kw["std"],
+                                          std_mode=kw["std_mode"], std_value=kw["std_value"], smean=spatial)
         _all_reduce_sum(grad, ctx.group)
         return grad.to(lut.dtype), None, None, None, None
 

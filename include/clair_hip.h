@@ -167,14 +167,16 @@ int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float max_code, i
  *   partner lists (CSR over samples): for sample n, entries partner_offsets[n] .. partner_offsets[n+1]-1 give the
  *   other sample of every pair containing n (partner_sample_dev) and the pair id (partner_pair_dev: p when n is
  *   the pair's first image i, ~p when it is the second image j)
+ *   std_dev / params->std_mode: uncertainties, read only with params->use_uncertainty_weighting; the weights
+ *   1/(err + 1e-6) then depend on the LUT (relative loss), and the backward needs smean_dev (P, C) float64 = the
+ *   spatial means of the forward:  d mean = sum m [w dv + (v - mean) dw] / sum w m.  smean_dev may be NULL otherwise.
  *   lut_grad_dev (C, L) float64, ACCUMULATED (+=)
- * Unsupported (CT_ERR_UNSUPPORTED): use_uncertainty_weighting with stds (the weights then depend on the LUT).
  */
 int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
-                         const ct_geometry *geom, const ct_icrf *icrf, const double *ratio_dev, int32_t n_pairs,
-                         const int32_t *partner_offsets_dev, const int32_t *partner_sample_dev,
+                         const ct_geometry *geom, const float *std_dev, const ct_icrf *icrf, const double *ratio_dev,
+                         int32_t n_pairs, const int32_t *partner_offsets_dev, const int32_t *partner_sample_dev,
                          const int32_t *partner_pair_dev, const ct_pair_params *params, const double *coef_dev,
-                         double *lut_grad_dev, void *stream);
+                         const double *smean_dev, double *lut_grad_dev, void *stream);
 
 /*
  * Flat-field correction epilogues (clair_torch/inference/hdr_merge.py:131-153, linearization.py:48-57,118-130;

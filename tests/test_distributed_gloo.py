@@ -51,7 +51,7 @@ def _install_stand_ins(whole_x):
         return torch.from_numpy(np.ascontiguousarray(sums[..., :5]))
 
     @torch.enable_grad()  # called from inside autograd.Function.backward, where grad mode is off
-    def fake_grad(stack, pairs, coef, *, lut, interp, lower, upper, use_relative, max_code=None, tile=None):
+    def fake_grad(stack, pairs, coef, *, lut, interp, lower, upper, use_relative, max_code=None, tile=None, **_unused):
         lut_t = lut.detach().clone().requires_grad_(True)
         r0 = 0 if tile is None else tile.row_offset
         lin = oe.icrf_forward(whole_x, lut_t, interp)[:, :, r0:r0 + stack.shape[2]]  # rows picked on the whole image

@@ -92,6 +92,45 @@ def test_linearity_loss_and_lut_gradient(dev, mode, rel):
     assert torch.equal(lin2.detach(), lin.detach())
 
 
+@pytest.mark.parametrize("mode", ["linear", "catmull"])
+@pytest.mark.parametrize("rel", [True, False])
+def test_uncertainty_weighted_loss_and_gradient(dev, mode, rel):
+    """use_uncertainty_weighting=True with uncertainty images (train_icrf's default): the weights 1/(err+1e-6)
+    depend on the LUT for the relative loss; loss and LUT gradient against the reference's autograd."""
+    from clair_torch_amd.training import linearity_loss
+    g = golden("training")
+    stack, _ = _inputs(g, dev)
+    pairs, _ = _pairs(g, dev, 0.25)
+    lut = torch.from_numpy(g["train_lut0"]).to(dev).requires_grad_(True)
+    lin, spatial = linearity_loss(lut, stack, pairs, interp=mode, lower=1 / 255, upper=254 / 255, use_relative=rel,
+                                  use_unc_weight=True, std_mode="multiplier", std_value=0.05)
+    key = f"train_multiplier_{mode}_{'rel' if rel else 'abs'}_unc"
+    assert_parity(lin.detach().cpu().numpy(), g[key + "_linloss"], rtol=1e-5, norm_tol=2e-6, what=key + " linloss")
+    assert_parity(spatial.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " spatial")
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert_parity(grad.cpu().numpy(), g[key + "_lingrad"], norm_tol=5e-5, elem_tol=5e-4, what=key + " lingrad")
+
+
+def test_train_icrf_uncertainty_weighted_run(dev):
+    """Five epochs with use_uncertainty_weighting=True and MULTIPLIER uncertainties vs the reference's run."""
+    from clair_torch_amd.common.enums import InterpMode, MissingStdMode
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.training import train_icrf
+    from oracle import ct_oracle as oc
+    g = golden("training")
+    x = torch.from_numpy(oc.normalize_codes(g["train_codes"]))
+    ds = StackDataset(x, g["train_exposures"].tolist(), missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05)
+    loader = DataLoader(ds, batch_size=x.shape[0], shuffle=False, collate_fn=custom_collate)
+    model = ICRFModelDirect(n_points=256, channels=3, interpolation_mode=InterpMode.LINEAR, initial_power=2.5).to(dev)
+    opts = [torch.optim.Adam(model.channel_params(c), lr=1e-3, amsgrad=False) for c in range(3)]
+    train_icrf(loader, x.shape[0], "cuda", model, optimizers=opts, use_relative_linearity_loss=True,
+               use_uncertainty_weighting=True, epochs=5, patience=200, alpha=10.0, exposure_ratio_threshold=0.25,
+               verbose=False)
+    ref = g["trainloop_multiplier_unc_icrf"]
+    assert np.max(np.abs(model.icrf.detach().cpu().numpy() - ref)) < 5e-6
+
+
 def test_lut_gradient_vs_eager_oracle_large(dev):
     """A bigger, ragged case (plane not a multiple of the tile, 9 exposures, 64-sample LUT) against the eager
     float64-residual oracle; also checks the tile decomposition: two row bands sum to the whole."""
