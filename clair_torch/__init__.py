@@ -10,6 +10,8 @@ _ALIASES = {
     "clair_torch.common.enums": "clair_torch_amd.common.enums",
     "clair_torch.common.transforms": "clair_torch_amd.common.transforms",
     "clair_torch.common.general_functions": "clair_torch_amd.common.general_functions",
+    "clair_torch.common.statistics": "clair_torch_amd.common.statistics",
+    "clair_torch.inference.inferential_statistics": "clair_torch_amd.inference.inferential_statistics",
     "clair_torch.datasets": "clair_torch_amd.datasets",
     "clair_torch.datasets.collate": "clair_torch_amd.datasets.collate",
     "clair_torch.models": "clair_torch_amd.models",

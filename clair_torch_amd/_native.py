@@ -19,7 +19,7 @@ ERR_NO_GRADIENT_PATH = -4
 
 EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd",
            "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_flatfield_sums",
-           "ct_flatfield_apply")
+           "ct_flatfield_apply", "ct_video_stats_batch")
 
 
 class Geometry(ctypes.Structure):
@@ -82,6 +82,8 @@ def load():
     lib.ct_flatfield_sums.argtypes = [vp, i32, vp, i32, i64, vp, vp]
     lib.ct_flatfield_apply.restype = i32
     lib.ct_flatfield_apply.argtypes = [vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i64, vp]
+    lib.ct_video_stats_batch.restype = i32
+    lib.ct_video_stats_batch.argtypes = [vp, i32, f32, i32, gp, ip, f32, vp, vp, vp]
     if lib.ct_abi_version() != 1:
         raise NativeLibraryError(f"{path}: ABI version {lib.ct_abi_version()} != 1; rebuild the library")
     _lib = lib

@@ -364,3 +364,28 @@ def flatfield_correct(value: torch.Tensor, var_or_std: Optional[torch.Tensor], f
                                           _ptr(flat), _ptr(flat_std), _ptr(flat_mean), _ptr(through), c, plane, _stream(dev))
     nv.check(rc, "ct_flatfield_apply")
     return value, var_or_std
+
+
+# ---- streaming video statistics -----------------------------------------------------------------------------------
+def video_stats_batch(frames: torch.Tensor, mean_state: torch.Tensor, m2_state: torch.Tensor, frames_before: int, *,
+                      lut: Optional[torch.Tensor] = None, interp: Optional[str] = None,
+                      max_code: Optional[float] = None, tile: Optional[TileGeometry] = None):
+    """ct_video_stats_batch: merge one batch of frames into the running (mean, m2) float32 state in place."""
+    _check_stack(frames, "frames")
+    b, c, h, w = frames.shape
+    dev = frames.device
+    frames = frames.contiguous()
+    if frames.dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if frames.dtype == torch.uint8 else 65535.0
+    for name, t in (("mean_state", mean_state), ("m2_state", m2_state)):
+        _require_device(t, name)
+        if t.dtype != torch.float32 or tuple(t.shape) != (c, h, w) or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous float32 (C,H,W) tensor")
+    icrf, lut_keep = _icrf_struct(lut, interp, c)
+    geom = _geometry(frames, tile)
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_video_stats_batch(_ptr(frames), _DTYPE[frames.dtype], float(max_code or 1.0), b,
+                                            ctypes.byref(geom), ctypes.byref(icrf), float(frames_before),
+                                            _ptr(mean_state), _ptr(m2_state), _stream(dev))
+    nv.check(rc, "ct_video_stats_batch")
+    del lut_keep

@@ -198,6 +198,18 @@ int ct_flatfield_apply(void *value_dev, int32_t value_is_f64, int64_t n_frames, 
                        const float *flat_mean_dev, const double *through_mean_dev, int32_t channels, int64_t plane,
                        void *stream);
 
+/*
+ * ct_video_stats_batch -- loop body of compute_video_mean_and_std
+ * (clair_torch/inference/inferential_statistics.py:38-47): optional ICRF linearization of a batch of frames and the
+ * unweighted WBOMeanVar update (clair_torch/common/statistics.py:213-259), float32 like the reference.
+ *   frames_dev (B, C, H_tile, W); frames_before = number of frames already merged (0 for the first batch)
+ *   mean_state_dev, m2_state_dev (C, H_tile, W) float32, updated in place.
+ * After the last batch: mean = mean_state, std of the mean = sqrt(m2 / (n - 1)) / sqrt(n)  (SAMPLE_FREQUENCY).
+ */
+int ct_video_stats_batch(const void *frames_dev, int32_t dtype, float max_code, int32_t batch, const ct_geometry *geom,
+                         const ct_icrf *icrf, float frames_before, float *mean_state_dev, float *m2_state_dev,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,3 +175,25 @@ def training_loss(vals, stds, exposures, lut, mode=LINEAR, ratio_threshold=0.25,
     lin_loss = torch.sqrt((sp ** 2).sum(dim=0))
     mono, rng, endp, smooth = curve_penalties(lut)
     return lin_loss + alpha * mono + beta * rng + gamma * endp + delta * smooth, lin_loss, sp
+
+
+def video_mean_std(frames, lut, mode, batch_sizes):
+    """compute_video_mean_and_std (clair_torch/inference/inferential_statistics.py:19-49): unweighted WBOMeanVar over
+    batches of frames (clair_torch/common/statistics.py:213-259), SAMPLE_FREQUENCY variance, std of the mean."""
+    mean_a = w_a = m2_a = 0.0
+    k = 0
+    with torch.inference_mode():
+        for b in batch_sizes:
+            x = frames[k:k + b]
+            k += b
+            if lut is not None:
+                x = icrf_forward(x, lut, mode)
+            mean_b = x.mean(dim=0, keepdim=True)
+            w_b = torch.full_like(mean_b, float(b))
+            m2_b = ((x - mean_b) ** 2).sum(dim=0, keepdim=True)
+            w = w_a + w_b
+            m2_a = m2_a + m2_b + (w_a * w_b / w) * (mean_b - mean_a) ** 2
+            mean_a = mean_a + (w_b / w) * (mean_b - mean_a)
+            w_a = w
+    var = m2_a * (1 / (w_a - 1))
+    return mean_a.squeeze(0), torch.sqrt(var.squeeze(0)) / (k ** 0.5)

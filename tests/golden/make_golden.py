@@ -450,10 +450,46 @@ def gen_flatfield(out):
             out[f"fflin_{fsname}_{sname}_std"] = np.stack(sds)
 
 
+def gen_video_stats(out):
+    """compute_video_mean_and_std (inference/inferential_statistics.py:19-49) and WBOMeanVar known answers
+    (common/statistics.py:112-259; the reference's tests/unit/common/test_statistics.py:98-219 pin the same class)."""
+    from clair_torch.inference.inferential_statistics import compute_video_mean_and_std
+    from clair_torch.common.statistics import WBOMeanVar
+    from clair_torch.common.enums import VarianceMode
+    gen = torch.Generator().manual_seed(707)
+    lut = lut_rows((2.2, 2.4, 2.6))
+    out["vid_lut"] = lut.numpy()
+    f, c, h, w = 11, 3, 9, 14
+    base = torch.rand((c, h, w), generator=gen)
+    codes = (base.unsqueeze(0) * 200 + 20 + 6 * torch.randn((f, c, h, w), generator=gen)).round().clamp(0, 255).to(torch.int32)
+    out["vid_codes"] = codes.numpy().astype(np.uint8)
+    frames = [normalize_tensor(codes[i].float(), max_val=255, min_val=0) for i in range(f)]
+    for mname in ("nomodel", "linear", "catmull"):
+        for bname, bs in (("b4", 4), ("b11", 11), ("b1", 1)):
+            ds = MemoryStack([v.clone() for v in frames], None, [1.0] * f)
+            loader = DataLoader(ds, batch_size=bs, shuffle=False, collate_fn=custom_collate)
+            model = None if mname == "nomodel" else ICRFModelDirect(icrf=lut.clone(), interpolation_mode=MODES[mname])
+            mean, std = compute_video_mean_and_std(loader, "cpu", model)
+            out[f"vid_{mname}_{bname}_mean"], out[f"vid_{mname}_{bname}_std"] = mean.numpy(), std.numpy()
+    # WBOMeanVar with weights, three variance modes, ragged batches (float64 like the reference's tests)
+    vals = torch.rand((10, 2, 3), generator=gen, dtype=torch.float64)
+    wts = 0.5 + torch.rand((10, 2, 3), generator=gen, dtype=torch.float64)
+    out["wbv_vals"], out["wbv_wts"] = vals.numpy(), wts.numpy()
+    for mode in (VarianceMode.POPULATION, VarianceMode.SAMPLE_FREQUENCY, VarianceMode.RELIABILITY_WEIGHTS):
+        for weighted in (True, False):
+            hnd = WBOMeanVar(dim=0, variance_mode=mode)
+            k = 0
+            for b in (4, 3, 3):
+                hnd.update_values(vals[k:k + b], wts[k:k + b] if weighted else None)
+                k += b
+            tag = f"wbv_{mode.name.lower()}_{'w' if weighted else 'u'}"
+            out[tag + "_mean"], out[tag + "_var"] = hnd.mean.numpy(), hnd.variance().numpy()
+
+
 def main():
     for name, fn in (("model_forward", gen_model_forward), ("merge", gen_merge), ("merge_c1", gen_merge_c1),
                      ("linearize", gen_linearize), ("training", gen_training), ("helpers", gen_helpers),
-                     ("flatfield", gen_flatfield)):
+                     ("flatfield", gen_flatfield), ("video_stats", gen_video_stats)):
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

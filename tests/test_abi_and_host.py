@@ -253,3 +253,38 @@ def test_oracle_tiles_equal_whole():
         assert np.array_equal(m_t, mean[:, r0:r1]) and np.array_equal(s_t, std[:, r0:r1])
     m_bad, _ = oc.hdr_merge(np.ascontiguousarray(x[:, :, 4:9]), np.ascontiguousarray(sd[:, :, 4:9]), t, lut, "linear", True)
     assert not np.array_equal(m_bad, mean[:, 4:9])
+
+
+def test_wbo_accumulators_match_reference_vectors():
+    """WBOMean / WBOMeanVar (API utilities) against values recorded from the reference's classes, all three variance
+    modes, weighted and unweighted, ragged batches; plus the reference tests' plain-mean property
+    (tests/unit/common/test_statistics.py:31-78)."""
+    from _util import golden
+    from clair_torch_amd.common import VarianceMode, WBOMean, WBOMeanVar
+    g = golden("video_stats")
+    vals, wts = torch.from_numpy(g["wbv_vals"]), torch.from_numpy(g["wbv_wts"])
+    for mode in (VarianceMode.POPULATION, VarianceMode.SAMPLE_FREQUENCY, VarianceMode.RELIABILITY_WEIGHTS):
+        for weighted in (True, False):
+            h = WBOMeanVar(dim=0, variance_mode=mode)
+            k = 0
+            for b in (4, 3, 3):
+                h.update_values(vals[k:k + b], wts[k:k + b] if weighted else None)
+                k += b
+            tag = f"wbv_{mode.name.lower()}_{'w' if weighted else 'u'}"
+            assert np.allclose(h.mean.numpy(), g[tag + "_mean"], rtol=1e-14, atol=0)
+            assert np.allclose(h.variance().numpy(), g[tag + "_var"], rtol=1e-12, atol=0)
+    gh = golden("helpers")
+    v, w = torch.from_numpy(gh["wbo_vals"]), torch.from_numpy(gh["wbo_wts"])
+    for weighted in (True, False):
+        h = WBOMean(dim=0)
+        k = 0
+        for b in (4, 3, 2):
+            m = h.update_values(v[k:k + b], w[k:k + b] if weighted else None)
+            k += b
+        assert np.allclose(m.numpy(), gh[f"wbo_mean_{'w' if weighted else 'u'}"], rtol=1e-14, atol=0)
+    h = WBOMean(dim=0)
+    data = torch.arange(12, dtype=torch.float64).view(6, 2)
+    h.update_values(data[:4])
+    assert torch.allclose(h.update_values(data[4:]).squeeze(0), data.mean(dim=0), atol=1e-8)
+    with pytest.raises(TypeError):
+        WBOMean(dim=(0, 1))

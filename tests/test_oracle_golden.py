@@ -246,3 +246,14 @@ def test_flatfield_epilogues_vs_golden():
             lc, sc = oc.flatfield_linearize(lin, so, flat, fs)
             assert_parity(lc, g[f"fflin_{fsname}_{sname}_val"], rtol=2e-7, norm_tol=1e-7, what="ff lin")
             assert_parity(sc, g[f"fflin_{fsname}_{sname}_std"], rtol=1e-6, norm_tol=1e-6, what="ff lin std")
+
+
+@pytest.mark.parametrize("mname", ["nomodel", "linear", "catmull"])
+def test_video_mean_std_eager_oracle(mname):
+    g = golden("video_stats")
+    x = torch.from_numpy(oc.normalize_codes(g["vid_codes"]))
+    lut = None if mname == "nomodel" else torch.from_numpy(g["vid_lut"])
+    for bname, sizes in (("b4", [4, 4, 3]), ("b11", [11]), ("b1", [1] * 11)):
+        mean, std = oe.video_mean_std(x, lut, mname if lut is not None else "linear", sizes)
+        assert np.array_equal(mean.numpy(), g[f"vid_{mname}_{bname}_mean"])
+        assert_parity(std.numpy(), g[f"vid_{mname}_{bname}_std"], rtol=1e-6, norm_tol=1e-7, what="video std")
