@@ -212,13 +212,17 @@ def measured_traffic(key):
         return None
 
 
+def _dist_on():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def barrier(world):
-    if world > 1:
+    if _dist_on():
         torch.distributed.barrier()
 
 
 def max_over_ranks(value, world, dev):
-    if world == 1:
+    if not _dist_on():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -226,7 +230,7 @@ def max_over_ranks(value, world, dev):
 
 
 def gather_stats(stats, world):
-    if world == 1:
+    if not _dist_on():
         return stats.unsqueeze(0)
     out = [torch.empty_like(stats) for _ in range(world)]
     torch.distributed.all_gather(out, stats.contiguous())
@@ -260,7 +264,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
     from clair_torch_amd import _native
@@ -269,7 +274,7 @@ def main():
     out = fn(args, rank, world, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if _dist_on():
         torch.distributed.destroy_process_group()
 
 

@@ -11,6 +11,7 @@ _ALIASES = {
     "clair_torch.common.transforms": "clair_torch_amd.common.transforms",
     "clair_torch.common.general_functions": "clair_torch_amd.common.general_functions",
     "clair_torch.common.statistics": "clair_torch_amd.common.statistics",
+    "clair_torch.common.data_io": "clair_torch_amd.common.data_io",
     "clair_torch.inference.inferential_statistics": "clair_torch_amd.inference.inferential_statistics",
     "clair_torch.datasets": "clair_torch_amd.datasets",
     "clair_torch.datasets.collate": "clair_torch_amd.datasets.collate",

@@ -18,6 +18,17 @@ class MissingStdMode(Enum):
     MULTIPLIER = auto()
 
 
+class ChannelOrder(Enum):
+    RGB = auto()
+    BGR = auto()
+    ANY = auto()
+
+
+class DimensionOrder(Enum):
+    BCS = auto()  # batch, channel, spatial (PyTorch)
+    BSC = auto()  # batch, spatial, channel (OpenCV)
+
+
 class VarianceMode(Enum):
     POPULATION = auto()
     SAMPLE_FREQUENCY = auto()

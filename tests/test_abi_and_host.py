@@ -288,3 +288,44 @@ def test_wbo_accumulators_match_reference_vectors():
     assert torch.allclose(h.update_values(data[4:]).squeeze(0), data.mean(dim=0), atol=1e-8)
     with pytest.raises(TypeError):
         WBOMean(dim=(0, 1))
+
+
+def test_icrf_txt_io_layouts_and_errors(tmp_path):
+    """load_icrf_txt / save_icrf_txt: on-disk (L, C) BGR by default <-> in-memory (C, L) RGB; error types as the
+    reference's tests expect (tests/unit/common/test_data_io.py:18-66)."""
+    from clair_torch_amd.common import ChannelOrder, DimensionOrder, load_icrf_txt, save_icrf_txt
+    from clair_torch_amd.common.typecheck import TypeCheckError
+    with pytest.raises(FileNotFoundError, match="doesn't exist"):
+        load_icrf_txt(tmp_path / "missing.txt")
+    with pytest.raises(ValueError, match="Expected a filepath"):
+        load_icrf_txt(tmp_path)
+    csv = tmp_path / "data.csv"
+    csv.write_text("0.0 0.1 0.2")
+    with pytest.raises(ValueError, match="Expected .txt filetype"):
+        load_icrf_txt(csv)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("this is not numeric data")
+    with pytest.raises(IOError, match="Failed to load NumPy array"):
+        load_icrf_txt(bad)
+    good = tmp_path / "icrf.txt"
+    np.savetxt(good, np.tile([0.1, 0.2, 0.3], (256, 1)).astype(np.float32))
+    with pytest.raises(TypeCheckError):
+        load_icrf_txt(good, source_channel_order="invalid channel order")
+    base = torch.from_numpy(np.tile([0.1, 0.2, 0.3], (256, 1))).float()
+    for co in (ChannelOrder.RGB, ChannelOrder.BGR, ChannelOrder.ANY):
+        for do in (DimensionOrder.BSC, DimensionOrder.BCS):
+            ref = base
+            if do == DimensionOrder.BSC:
+                ref = ref.transpose(0, 1)
+            if co == ChannelOrder.BGR:
+                ref = ref[[2, 1, 0], :]
+            got = load_icrf_txt(good, source_channel_order=co, source_dimension_order=do)
+            assert got.shape == ref.shape and torch.allclose(got, ref)
+    curve = torch.stack([torch.linspace(0, 1, 16) ** p for p in (1.5, 2.0, 2.5)])
+    out = tmp_path / "saved.txt"
+    save_icrf_txt(curve, out)
+    on_disk = np.loadtxt(out)
+    assert on_disk.shape == (16, 3) and np.allclose(on_disk[:, 0], curve[2].numpy())   # column 0 = blue
+    assert torch.allclose(load_icrf_txt(out), curve)
+    save_icrf_txt(curve, out, ChannelOrder.RGB, DimensionOrder.BCS)
+    assert torch.allclose(load_icrf_txt(out, ChannelOrder.RGB, DimensionOrder.BCS), curve)
