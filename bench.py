@@ -238,6 +238,11 @@ def gather_stats(stats, world):
 
 
 def main():
+    # Exactly ONE line may reach stdout (the JSON).  RCCL prints a version banner to fd 1 when its communicator
+    # comes up, so fd 1 is pointed at stderr for the whole run and the JSON is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -273,7 +278,8 @@ def main():
     fn = {"merge": run_merge, "linearize": run_linearize, "train": run_train}[args.workload]
     out = fn(args, rank, world, dev)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if _dist_on():
         torch.distributed.destroy_process_group()
 

@@ -186,3 +186,32 @@ def test_merge_full_size_properties(dev):
     assert_parity(m_c.cpu().numpy(), m_o, rtol=1e-5, norm_tol=1e-6, what="C2 crop mean")
     assert_parity(s_c.cpu().numpy(), s_o, rtol=1e-5, norm_tol=1e-5, elem_tol=2e-5, what="C2 crop std")
     del tile
+
+
+def test_config_c5_eight_bands_equal_whole_image(dev):
+    """BASELINE config C5 on one GPU: the 32 x 8192 x 8192 x 3 uint16 stack (12.9 GB, resident in HBM) merged as one
+    image and as the 8 row bands of 1024 rows the 8 ranks would hold.  Bands are generated independently from the
+    global pixel coordinates (as each rank would) and must reproduce the whole image bit for bit; the per-band
+    statistics vector C5 gathers is checked to sum to the whole image's."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    n, c, h, w, ranks = 32, 3, 8192, 8192, 8
+    lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]).to(dev)
+    kw = dict(lut=lut, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+    whole, exposures = synthetic_exposure_stack(n, c, h, w, bits=16, stops_per_step=0.25, seed=1238, device=dev)
+    t = torch.tensor(exposures, dtype=torch.float64, device=dev)
+    mean, std = ops.hdr_merge_batch(whole, t, **kw)
+    del whole
+    torch.cuda.empty_cache()
+    band_rows = h // ranks
+    sum_mean = torch.zeros(c, dtype=torch.float64, device=dev)
+    for r in range(ranks):
+        r0 = r * band_rows
+        band, _ = synthetic_exposure_stack(n, c, h, w, bits=16, stops_per_step=0.25, seed=1238, device=dev,
+                                           row_range=(r0, r0 + band_rows))
+        m_b, s_b = ops.hdr_merge_batch(band, t, tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw)
+        assert torch.equal(m_b, mean[:, r0:r0 + band_rows]) and torch.equal(s_b, std[:, r0:r0 + band_rows]), r
+        sum_mean += m_b.sum(dim=(1, 2))
+        del band, m_b, s_b
+    assert torch.allclose(sum_mean, mean.sum(dim=(1, 2)), rtol=1e-12)
+    assert torch.isfinite(mean).all() and torch.isfinite(std).all()
