@@ -229,6 +229,10 @@ struct PartnerEntry {
     float sm;   // spatial mean of the pair (only read by the uncertainty-weighted backward)
 };
 
+// Design note (measured, C3 shape): evaluating every pair ONCE (own-side gradient in a register, partner-side via
+// ds_add_f32 into a per-tile (sample, pixel) buffer) was tried and is 2-3.5x SLOWER (64-99 ms vs 28.6 ms): one LDS
+// float atomic per pair-pixel serialises the LDS pipe.  Evaluating each pair from both of its samples costs ~1.6x the
+// VALU work but keeps the inner loop free of LDS writes.
 // 512 threads (8 waves) per workgroup: at N = 64 the staged tile + partner entries take ~90 KB of LDS, so only one
 // workgroup fits a CU; eight waves keep two per SIMD to cover the LDS latency of the partner loop.
 constexpr int kBwdBlock = 512;

@@ -215,3 +215,26 @@ def test_config_c5_eight_bands_equal_whole_image(dev):
         del band, m_b, s_b
     assert torch.allclose(sum_mean, mean.sum(dim=(1, 2)), rtol=1e-12)
     assert torch.isfinite(mean).all() and torch.isfinite(std).all()
+
+
+@pytest.mark.parametrize("n_points", [2, 100, 1000])
+@pytest.mark.parametrize("dtype", ["u8", "u16"])
+def test_merge_unusual_lut_sizes(dev, n_points, dtype):
+    """LUT lengths other than 256: the code->LUT-coordinate fold is only taken when it reproduces the reference's
+    float32 index for every code (ct_index_constants); either way the result must match the oracle, knots included."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(n_points)
+    n, c, h, w = 6, 3, 16, 24
+    hi = 256 if dtype == "u8" else 65536
+    codes = rng.integers(0, hi, size=(n, c, h, w)).astype(np.uint8 if dtype == "u8" else np.uint16)
+    codes.reshape(-1)[:4] = [0, hi - 1, (hi - 1) // 3, (hi - 1) // 5]        # exact knots / ends
+    x = oc.normalize_codes(codes)
+    t = 0.001 * 2.0 ** np.arange(n)
+    lut = np.stack([np.linspace(0, 1, n_points, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
+    for mode in ("linear", "lookup", "catmull"):
+        mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, mode, True)
+        mean, std = ops.hdr_merge_batch(torch.from_numpy(codes).to(dev), torch.from_numpy(t), lut=torch.from_numpy(lut).to(dev),
+                                        interp=mode, std_mode="multiplier", std_value=0.05)
+        assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"L={n_points} {mode} mean")
+        assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, elem_tol=5e-5, what=f"L={n_points} {mode} std")
