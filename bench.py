@@ -116,7 +116,7 @@ def run_merge(args, rank, world, dev):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C2: {n_exp}-exposure {h}x{w}x3 uint16 stack per GPU, merge+uncertainty "
                                f"(LINEAR ICRF 3x256, Gaussian weights, sigma=0.05*x in-kernel, float64 mean + float32 std out)",
-                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel<uint16,4,LINEAR,GAUSS,MULTIPLIER>",
+                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel<uint16, V=8, LINEAR, GAUSS, MULTIPLIER, FOLD, PF=2>",
                    "finite": bool(torch.isfinite(gathered).all())},
         "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
