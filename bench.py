@@ -84,6 +84,15 @@ def run_merge(args, rank, world, dev):
     t_dev = torch.tensor(exposures, dtype=torch.float64, device=dev)
     tile = ops.TileGeometry(h_global=h_global, row_offset=rank * h) if world > 1 else None
     kw = dict(lut=lut, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05, tile=tile)
+    in_bytes = 2
+    if args.input == "f32":  # what the reference's own DataLoader delivers: normalised float32 pixels
+        codes = codes.to(torch.int32).to(torch.float32) / 65535.0
+        in_bytes = 4
+    if args.std == "explicit":
+        kw.update(std=(codes.to(torch.float32) * (0.05 / (65535.0 if args.input == "u16" else 1.0))), std_mode="explicit")
+        in_bytes += 4
+    elif args.std == "none":
+        kw.update(std_mode="none")
 
     def step():
         return ops.hdr_merge_batch(codes, t_dev, **kw)
@@ -104,23 +113,28 @@ def run_merge(args, rank, world, dev):
     elapsed = max_over_ranks(elapsed, world, dev)
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     # per-band statistics gathered over RCCL (untimed; C5's "gather of per-tile stats")
+    if std is None:
+        std = torch.zeros_like(mean, dtype=torch.float32)
     stats = torch.stack([mean.amin(dim=(1, 2)), mean.amax(dim=(1, 2)), mean.sum(dim=(1, 2)),
                          std.double().amin(dim=(1, 2)), std.double().amax(dim=(1, 2)), std.double().sum(dim=(1, 2))])
     gathered = gather_stats(stats, world)
     px = h * w
-    bytes_alg = n_exp * c * px * 2 + c * px * (8 + 4)  # uint16 stack read + float64 mean + float32 std written
+    # stack (+ explicit std) read + float64 mean (+ float32 std) written
+    bytes_alg = n_exp * c * px * in_bytes + c * px * (8 + (0 if args.std == "none" else 4))
     out = {
         "metric": "MPix/s HDR-merged (+uncertainty) at N=32 4K RGB", "value": round(world * px * args.steps / elapsed / 1e6, 1),
         "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2: {n_exp}-exposure {h}x{w}x3 uint16 stack per GPU, merge+uncertainty "
-                               f"(LINEAR ICRF 3x256, Gaussian weights, sigma=0.05*x in-kernel, float64 mean + float32 std out)",
+        "config": {"workload": f"C2: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU, "
+                               f"merge{'' if args.std == 'none' else '+uncertainty'} (LINEAR ICRF 3x256, Gaussian weights, "
+                               f"sigma: {args.std}, float64 mean + float32 std out)",
                    "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel<uint16, V=8, LINEAR, GAUSS, MULTIPLIER, FOLD, PF=2>",
                    "finite": bool(torch.isfinite(gathered).all())},
         "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic("merge_c2"), "bytes_per_launch": bytes_alg,
+                     "traffic": measured_traffic("merge_c2") if (args.input, args.std) == ("u16", "multiplier") else None,
+                     "bytes_per_launch": bytes_alg,
                      "kernel_ms": round(kernel_ms, 4)},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -248,6 +262,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="merge", choices=["merge", "linearize", "train"])
+    ap.add_argument("--input", default="u16", choices=["u16", "f32"], help="merge: stack element type (default = C2)")
+    ap.add_argument("--std", default="multiplier", choices=["multiplier", "explicit", "none"],
+                    help="merge: uncertainty source (default = C2: sigma = 0.05 x derived in-kernel)")
     ap.add_argument("--exposures", type=int, default=32)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)

@@ -148,9 +148,16 @@ __device__ __forceinline__ int lut_row(uint32_t q_global, int channel, int C)
 
 // Streaming store of a whole packet: outputs are written once and never re-read by these kernels, so they are
 // stored non-temporally (no L2 allocation competing with the input stream).
+#ifndef CT_STREAM_STORES_NT
+#define CT_STREAM_STORES_NT 1
+#endif
 template <typename P>
 __device__ __forceinline__ void store_stream(P *dst, const P &v)
 {
+    if constexpr (!CT_STREAM_STORES_NT) {
+        *dst = v;
+        return;
+    }
     constexpr int kWords = sizeof(P) / 4;
     static_assert(sizeof(P) % 4 == 0, "packet must be dword sized");
     const uint32_t *src = reinterpret_cast<const uint32_t *>(&v);
