@@ -14,6 +14,7 @@ DTYPE_U8, DTYPE_U16, DTYPE_F32 = 0, 1, 2
 INTERP_LOOKUP, INTERP_LINEAR, INTERP_CATMULL, INTERP_NONE = 0, 1, 2, 3
 STD_NONE, STD_CONSTANT, STD_MULTIPLIER, STD_EXPLICIT = 0, 1, 2, 3
 WEIGHT_NONE, WEIGHT_GAUSS = 0, 1
+LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BGR = 0, 1, 2
 MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32 = 1, 2, 4
 ERR_NO_GRADIENT_PATH = -4
 
@@ -24,7 +25,8 @@ EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linear
 
 class Geometry(ctypes.Structure):
     _fields_ = [("channels", ctypes.c_int32), ("h_tile", ctypes.c_int64), ("width", ctypes.c_int64),
-                ("h_global", ctypes.c_int64), ("row_offset", ctypes.c_int64), ("image_stride", ctypes.c_int64)]
+                ("h_global", ctypes.c_int64), ("row_offset", ctypes.c_int64), ("image_stride", ctypes.c_int64),
+                ("layout", ctypes.c_int32)]
 
 
 class Icrf(ctypes.Structure):

@@ -16,6 +16,23 @@ class BaseTransform:
         raise NotImplementedError
 
 
+class CvToTorch(BaseTransform):
+    """OpenCV (H, W[, C]) BGR -> PyTorch (C, H, W) RGB (reference transforms.py / general_functions.py:315-335).
+    Applied to a collated batch (B, H, W, C) it acts per image.  As the first entry of ``gpu_transforms`` on raw
+    integer frames it is folded into the kernels' load stage (layout "nhwc_bgr") instead of being executed."""
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 2:
+            return x.unsqueeze(0)
+        if x.ndim in (3, 4) and x.shape[-1] == 3:
+            # torch has no uint16 indexing / flip kernels: reverse the channels on a same-width signed view
+            alias = {torch.uint16: torch.int16, torch.uint32: torch.int32}.get(x.dtype)
+            y = (x.view(alias) if alias else x).flip(-1)
+            y = y.view(x.dtype) if alias else y
+            return y.permute(2, 0, 1) if x.ndim == 3 else y.permute(0, 3, 1, 2)
+        raise ValueError(f"Unexpected image shape: {tuple(x.shape)}")
+
+
 class CastTo(BaseTransform):
     def __init__(self, data_type=None, device=None):
         if isinstance(data_type, str):
@@ -29,6 +46,11 @@ class CastTo(BaseTransform):
 
 
 class Normalize(BaseTransform):
+    """(x - min) / (max - min) * span + min_t (reference general_functions.py:359-388).  Executed as a torch op on a
+    GPU tensor the division by a scalar is a multiplication by its reciprocal (torch's GPU kernels), 1 ulp away from
+    the CPU result for some codes; when the kernels fold this transform (integer codes, see
+    ``fusable_code_normalisation``) they reproduce the CPU reference's correctly rounded division instead."""
+
     def __init__(self, max_val: Optional[float] = None, min_val: Optional[float] = None, target_range=(0.0, 1.0)):
         self.max_val, self.min_val, self.target_range = max_val, min_val, tuple(target_range)
 
@@ -41,6 +63,16 @@ class Normalize(BaseTransform):
             raise ValueError("Normalization range is zero (min == max); cannot normalize.")
         lo, hi = self.target_range
         return (x - min_val) / den * (hi - lo) + lo
+
+
+def fusable_layout(images: torch.Tensor, transforms):
+    """("nhwc_bgr", remaining transforms) when the list starts with CvToTorch on a (B,H,W,3) integer batch -- the
+    channel reversal and the HWC->CHW transpose are then done by the kernel's addressing -- else ("nchw", transforms)."""
+    ts = [t for t in transforms if t is not None]
+    if ts and isinstance(ts[0], CvToTorch) and images.ndim == 4 and images.shape[3] == 3 and \
+            images.dtype in (torch.uint8, torch.uint16):
+        return "nhwc_bgr", ts[1:]
+    return "nchw", ts
 
 
 def fusable_code_normalisation(images: torch.Tensor, transforms):

@@ -183,10 +183,21 @@ struct TileMap {
     uint32_t plane_local;  // H_tile * W
     uint32_t chan_skip;    // (H_global - H_tile) * W
     uint32_t base;         // row_offset * W
+    uint32_t layout;       // CT_LAYOUT_* of the input stack
+    uint32_t channels;     // C (used by the interleaved layouts)
     __device__ __forceinline__ void locate(uint32_t ql, int &channel, uint32_t &q_global) const
     {
         channel = (int)(ql / plane_local);
         q_global = ql + (uint32_t)channel * chan_skip + base;
+    }
+    // Memory element m of one image -> planar (C, H_tile, W) index.  For NCHW this is the identity; for the
+    // interleaved layouts element m is channel m % C of pixel m / C (channel order reversed for BGR).
+    __device__ __forceinline__ uint32_t planar_index(uint32_t m) const
+    {
+        if (layout == CT_LAYOUT_NCHW) return m;
+        const uint32_t pixel = m / channels, cm = m - pixel * channels;
+        const uint32_t c = layout == CT_LAYOUT_NHWC_BGR ? channels - 1 - cm : cm;
+        return c * plane_local + pixel;
     }
 };
 

@@ -26,6 +26,7 @@ struct LinArgs {
     float *lin_out;
     float *std_out;
     int64_t image_stride;
+    int64_t out_stride;         // elements between consecutive output frames (C * H_tile * W, planar)
     uint32_t q_begin, q_count;  // local element range of this launch (per frame)
     uint32_t n_frames;
     TileMap tile;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
     for (int e = 0; e < V; ++e) {
         int ch;
         uint32_t qg;
-        a.tile.locate(q0 + e, ch, qg);
+        a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
         row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
     }
     for (uint32_t f = blockIdx.y; f < a.n_frames; f += gridDim.y) {
@@ -77,8 +78,18 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
                 so.v[e] = STD == CT_STD_NONE ? 0.0f : sqrtf(gs * gs);
             }
         }
-        store_stream(reinterpret_cast<LPacket<float, V> *>(a.lin_out + off), lo);
-        if constexpr (WRITE_STD) store_stream(reinterpret_cast<LPacket<float, V> *>(a.std_out + off), so);
+        if (a.tile.layout != CT_LAYOUT_NCHW) {  // interleaved input -> planar outputs, element-wise stores
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int64_t oq = (int64_t)f * a.out_stride + a.tile.planar_index(q0 + e);
+                a.lin_out[oq] = lo.v[e];
+                if constexpr (WRITE_STD) a.std_out[oq] = so.v[e];
+            }
+            continue;
+        }
+        const int64_t ooff = (int64_t)f * a.out_stride + q0;
+        store_stream(reinterpret_cast<LPacket<float, V> *>(a.lin_out + ooff), lo);
+        if constexpr (WRITE_STD) store_stream(reinterpret_cast<LPacket<float, V> *>(a.std_out + ooff), so);
     }
 }
 
@@ -250,6 +261,7 @@ static int check_geom(const ct_geometry *g)
         return CT_ERR_INVALID_ARGUMENT;
     if (g->h_global * g->width * g->channels >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
     if (g->image_stride < g->h_tile * g->width * g->channels) return CT_ERR_INVALID_ARGUMENT;
+    if (g->layout < CT_LAYOUT_NCHW || g->layout > CT_LAYOUT_NHWC_BGR) return CT_ERR_INVALID_ARGUMENT;
     return CT_OK;
 }
 
@@ -259,6 +271,8 @@ static TileMap make_tile(const ct_geometry *g)
     t.plane_local = (uint32_t)(g->h_tile * g->width);
     t.chan_skip = (uint32_t)((g->h_global - g->h_tile) * g->width);
     t.base = (uint32_t)(g->row_offset * g->width);
+    t.layout = (uint32_t)g->layout;
+    t.channels = (uint32_t)g->channels;
     return t;
 }
 
@@ -288,6 +302,7 @@ extern "C" int ct_linearize_std(const void *frames_dev, int32_t dtype, float max
     a.lin_out = lin_out_dev;
     a.std_out = std_out_dev;
     a.image_stride = geom->image_stride;
+    a.out_stride = geom->h_tile * geom->width * geom->channels;
     a.n_frames = (uint32_t)n_frames;
     a.tile = make_tile(geom);
     a.channels = geom->channels;
@@ -324,6 +339,7 @@ extern "C" int ct_linearize_bwd(const float *x_dev, const float *grad_out_dev, i
     if (!grad_x_dev && !lut_grad_dev) return CT_OK;
     int rc = check_geom(geom);
     if (rc != CT_OK) return rc;
+    if (geom->layout != CT_LAYOUT_NCHW) return CT_ERR_UNSUPPORTED;
     const int interp = icrf->interp;
     if (interp < CT_INTERP_LOOKUP || interp > CT_INTERP_CATMULL || !icrf->lut_dev || icrf->n_points < 2)
         return CT_ERR_INVALID_ARGUMENT;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     for (int e = 0; e < V; ++e) {
         int ch;
         uint32_t qg;
-        a.tile.locate(q0 + e, ch, qg);
+        a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
         row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
     }
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     float std_o[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        const uint32_t q = q0 + e;
+        const uint32_t q = a.tile.planar_index(q0 + e);  // state and outputs are planar (C, H, W)
         float Wb = W[e];
         if constexpr (!kGauss) Wb = (float)B;
         const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
@@ -291,7 +291,18 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
         mean_o[e] = mean;
         std_o[e] = sqrtf(var);
     }
-    if (finalize) {
+    if (finalize && a.tile.layout != CT_LAYOUT_NCHW) {
+        // interleaved input: the V elements of this thread belong to different planes -> element-wise stores
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const uint32_t q = a.tile.planar_index(q0 + e);
+            if (a.flags & CT_MERGE_MEAN_OUT_F32)
+                static_cast<float *>(a.mean_out)[q] = (float)mean_o[e];
+            else
+                static_cast<double *>(a.mean_out)[q] = mean_o[e];
+            if constexpr (kHasStd) a.std_out[q] = std_o[e];
+        }
+    } else if (finalize) {
         if (a.flags & CT_MERGE_MEAN_OUT_F32) {
             Packet<float, V> o;
 #pragma unroll
@@ -418,6 +429,7 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
     if (geom->channels <= 0 || geom->h_tile <= 0 || geom->width <= 0 || geom->h_global < geom->h_tile ||
         geom->row_offset < 0 || geom->row_offset + geom->h_tile > geom->h_global)
         return CT_ERR_INVALID_ARGUMENT;
+    if (geom->layout < CT_LAYOUT_NCHW || geom->layout > CT_LAYOUT_NHWC_BGR) return CT_ERR_INVALID_ARGUMENT;
     const int interp = icrf->interp;
     if (interp < CT_INTERP_LOOKUP || interp > CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
     if (interp != CT_INTERP_NONE && (!icrf->lut_dev || icrf->n_points < 2)) return CT_ERR_INVALID_ARGUMENT;
@@ -451,6 +463,8 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
     a.tile.plane_local = (uint32_t)plane_l;
     a.tile.chan_skip = (uint32_t)(plane_g - plane_l);
     a.tile.base = (uint32_t)(geom->row_offset * geom->width);
+    a.tile.layout = (uint32_t)geom->layout;
+    a.tile.channels = (uint32_t)geom->channels;
     a.batch = batch;
     a.channels = geom->channels;
     a.n_points = interp == CT_INTERP_NONE ? 2 : icrf->n_points;

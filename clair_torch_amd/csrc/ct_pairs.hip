@@ -516,6 +516,7 @@ static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, con
         return CT_ERR_INVALID_ARGUMENT;
     if (g->h_global * g->width * g->channels >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
     if (g->image_stride < g->h_tile * g->width * g->channels) return CT_ERR_INVALID_ARGUMENT;
+    if (g->layout != CT_LAYOUT_NCHW) return CT_ERR_UNSUPPORTED;
     if (icrf->interp < CT_INTERP_LOOKUP || icrf->interp > CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
     if (icrf->interp != CT_INTERP_NONE && (!icrf->lut_dev || icrf->n_points < 2)) return CT_ERR_INVALID_ARGUMENT;
     if (prm->std_mode < CT_STD_NONE || prm->std_mode > CT_STD_EXPLICIT) return CT_ERR_INVALID_ARGUMENT;
@@ -528,6 +529,8 @@ static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, con
     a.tile.plane_local = (uint32_t)(g->h_tile * g->width);
     a.tile.chan_skip = (uint32_t)((g->h_global - g->h_tile) * g->width);
     a.tile.base = (uint32_t)(g->row_offset * g->width);
+    a.tile.layout = CT_LAYOUT_NCHW;
+    a.tile.channels = (uint32_t)g->channels;
     a.plane_local = a.tile.plane_local;
     a.n_images = n_images;
     a.n_pairs = n_pairs;

@@ -163,6 +163,7 @@ extern "C" int ct_video_stats_batch(const void *frames_dev, int32_t dtype, float
     const int64_t Qg = geom->h_global * geom->width * geom->channels, Ql = geom->h_tile * geom->width * geom->channels;
     if (Qg >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
     if (geom->image_stride < Ql) return CT_ERR_INVALID_ARGUMENT;
+    if (geom->layout != CT_LAYOUT_NCHW) return CT_ERR_UNSUPPORTED;
     StatsArgs a{};
     a.frames = frames_dev;
     a.lut = icrf->lut_dev;
@@ -172,6 +173,8 @@ extern "C" int ct_video_stats_batch(const void *frames_dev, int32_t dtype, float
     a.tile.plane_local = (uint32_t)(geom->h_tile * geom->width);
     a.tile.chan_skip = (uint32_t)((geom->h_global - geom->h_tile) * geom->width);
     a.tile.base = (uint32_t)(geom->row_offset * geom->width);
+    a.tile.layout = CT_LAYOUT_NCHW;
+    a.tile.channels = (uint32_t)geom->channels;
     a.batch = batch;
     a.channels = geom->channels;
     a.n_points = interp == CT_INTERP_NONE ? 2 : icrf->n_points;

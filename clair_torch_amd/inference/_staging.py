@@ -3,7 +3,7 @@ from typing import Iterable, Optional
 
 import torch
 
-from ..common.transforms import fusable_code_normalisation
+from ..common.transforms import fusable_code_normalisation, fusable_layout
 
 
 def resolve_device(device) -> torch.device:
@@ -24,12 +24,22 @@ def normalise_transform_list(gpu_transforms) -> list:
     return [gpu_transforms]
 
 
-def stage_images(val_batch: torch.Tensor, device: torch.device, transforms: list):
+def stage_images(val_batch: torch.Tensor, device: torch.device, transforms: list, want_layout: bool = False):
     """Move the value batch to the device and run / fuse the device transforms.
 
     Returns (images, max_code): integer codes with their max_code when the transform list is the
-    CastTo(float32)+Normalize(max, 0) pair the kernels ingest directly, else float32 pixels and None."""
+    CastTo(float32)+Normalize(max, 0) pair the kernels ingest directly, else float32 pixels and None.
+    With ``want_layout`` a third value is returned: "nhwc_bgr" when the list additionally starts with CvToTorch
+    on raw (B,H,W,3) frames (the kernel then reads the interleaved BGR frames as they are), else "nchw"."""
     images = val_batch.to(device=device, non_blocking=True)
+    if want_layout:
+        layout, rest = fusable_layout(images, transforms)
+        if layout != "nchw":
+            max_code = fusable_code_normalisation(images, rest)
+            if max_code is not None:
+                return images, max_code, layout
+        out = stage_images(val_batch, device, transforms)
+        return out[0], out[1], "nchw"
     max_code = fusable_code_normalisation(images, transforms)
     if max_code is not None:
         return images, max_code
@@ -38,7 +48,7 @@ def stage_images(val_batch: torch.Tensor, device: torch.device, transforms: list
     if images.dtype in (torch.uint8, torch.uint16):
         raise TypeError("integer images reached the kernel without a Normalize transform; pass "
                         "gpu_transforms=[CastTo('float32'), Normalize(max_val=<max code>, min_val=0)]")
-    return images.to(torch.float32), None
+    return images.to(torch.float32).contiguous(), None
 
 
 def std_arguments(std_batch: Optional[torch.Tensor], dataset, device):

@@ -51,14 +51,17 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
         _, val_batch, std_batch, meta_batch = pending
         pending = next(batches, None)
         last = pending is None
-        images, max_code = stage_images(val_batch, dev, transforms)
+        images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
+        if std is not None and layout != "nchw":  # explicit std images come planar: take the generic path
+            images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
         if state is None and (not last or flat_field_dataset is not None):
-            state = ops.MergeState(tuple(images.shape[1:]), dev, with_variance=std_mode != "none")
+            chw = tuple(images.shape[1:]) if layout == "nchw" else (images.shape[3], images.shape[1], images.shape[2])
+            state = ops.MergeState(chw, dev, with_variance=std_mode != "none")
         result = ops.hdr_merge_batch(images, meta_batch["exposure_time"], lut=lut, interp=interp,
                                      gaussian_weight=weight_fn is not None, std=std, std_mode=std_mode,
                                      std_value=std_value, max_code=max_code, state=state,
-                                     finalize=last and flat_field_dataset is None, tile=tile)
+                                     finalize=last and flat_field_dataset is None, tile=tile, layout=layout)
     if flat_field_dataset is not None:
         return _flat_field_epilogue(state, flat_field_dataset, dataloader.dataset, dev, tile, group)
     mean, std = result

@@ -35,10 +35,12 @@ def linearize_dataset_generator(dataloader: DataLoader, device, icrf_model: ICRF
         flat = flat.to(dev)
         flat_std = flat_std.to(dev) if flat_std is not None else None
     for _, val_batch, std_batch, meta_batch in dataloader:
-        images, max_code = stage_images(val_batch, dev, transforms)
+        images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
+        if std is not None and layout != "nchw":  # explicit std images come planar: take the generic path
+            images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
         lin, lin_std = ops.linearize_frames(images, lut, interp, std=std, std_mode=std_mode, std_value=std_value,
-                                            max_code=max_code, want_std=True)
+                                            max_code=max_code, want_std=True, layout=layout)
         if flat is not None:  # linearization.py:118-130: mean is a constant, the image term is not rescaled
             ops.flatfield_correct(lin, lin_std, flat, flat_std, input_is_variance=False, through_mean=False)
         yield lin.squeeze().cpu(), lin_std.squeeze().cpu(), meta_batch

@@ -15,6 +15,9 @@ from . import _native as nv
 _INTERP = {"lookup": nv.INTERP_LOOKUP, "linear": nv.INTERP_LINEAR, "catmull": nv.INTERP_CATMULL, None: nv.INTERP_NONE}
 _STD = {"none": nv.STD_NONE, "constant": nv.STD_CONSTANT, "multiplier": nv.STD_MULTIPLIER, "explicit": nv.STD_EXPLICIT}
 _DTYPE = {torch.uint8: nv.DTYPE_U8, torch.uint16: nv.DTYPE_U16, torch.float32: nv.DTYPE_F32}
+# input stack layouts: planar (N,C,H,W) as the reference's tensors, or interleaved (N,H,W,C) as OpenCV decodes
+# (optionally BGR: the kernels then fold cv_to_torch's channel reversal into the load).  Outputs are always (C,H,W).
+_LAYOUT = {"nchw": nv.LAYOUT_NCHW, "nhwc": nv.LAYOUT_NHWC, "nhwc_bgr": nv.LAYOUT_NHWC_BGR}
 
 
 @dataclass
@@ -40,12 +43,21 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _geometry(stack: torch.Tensor, tile: Optional[TileGeometry]) -> nv.Geometry:
-    _, c, h, w = stack.shape
+def _chw(stack: torch.Tensor, layout: str):
+    if layout not in _LAYOUT:
+        raise ValueError(f"unknown layout {layout!r} (nchw, nhwc, nhwc_bgr)")
+    if layout == "nchw":
+        return stack.shape[1], stack.shape[2], stack.shape[3]
+    return stack.shape[3], stack.shape[1], stack.shape[2]
+
+
+def _geometry(stack: torch.Tensor, tile: Optional[TileGeometry], layout: str = "nchw") -> nv.Geometry:
+    c, h, w = _chw(stack, layout)
     hg, r0 = (h, 0) if tile is None else (tile.h_global, tile.row_offset)
     if r0 < 0 or r0 + h > hg:
         raise ValueError(f"tile rows [{r0}, {r0 + h}) do not fit a global height of {hg}")
-    return nv.Geometry(channels=c, h_tile=h, width=w, h_global=hg, row_offset=r0, image_stride=stack.stride(0))
+    return nv.Geometry(channels=c, h_tile=h, width=w, h_global=hg, row_offset=r0, image_stride=stack.stride(0),
+                       layout=_LAYOUT[layout])
 
 
 def _check_stack(stack: torch.Tensor, name="stack"):
@@ -84,14 +96,17 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
                     interp: Optional[str] = "linear", gaussian_weight: bool = True,
                     std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                     max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
-                    tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64):
+                    tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw"):
     """One batch of the HDR merge (ct_hdr_merge_batch).  Returns (mean, std|None) when ``finalize`` else None.
 
     stack (B,C,H,W) uint8/uint16 codes (give ``max_code``) or float32 pixels; exposures (B) any float dtype.
     ``state`` carries the streaming state across batches (None = single-batch merge).
+    ``layout`` "nhwc" / "nhwc_bgr": the stack is (B,H,W,C) as OpenCV decodes it (an explicit std stack likewise);
+    outputs stay planar (C,H,W).
     """
     _check_stack(stack)
-    b, c, h, w = stack.shape
+    b = stack.shape[0]
+    c, h, w = _chw(stack, layout)
     dev = stack.device
     if b < 1:
         raise ValueError("empty batch")
@@ -112,7 +127,7 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
     if exposure_dev.numel() != b:
         raise ValueError(f"{exposure_dev.numel()} exposure times for a batch of {b}")
     icrf, lut_keep = _icrf_struct(lut, interp, c)
-    geom = _geometry(stack, tile)
+    geom = _geometry(stack, tile, layout)
     has_std = std_mode != "none"
     first = state is None or state.batches == 0
     flags = (nv.MERGE_FIRST_BATCH if first else 0) | (nv.MERGE_FINALIZE if finalize else 0)
@@ -142,10 +157,13 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
 
 def linearize_frames(frames: torch.Tensor, lut: torch.Tensor, interp: str = "linear", *,
                      std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
-                     max_code: Optional[float] = None, want_std: bool = True, tile: Optional[TileGeometry] = None):
-    """ct_linearize_std on (F,C,H,W) frames -> (lin float32, std float32 | None); every frame is its own batch."""
+                     max_code: Optional[float] = None, want_std: bool = True, tile: Optional[TileGeometry] = None,
+                     layout: str = "nchw"):
+    """ct_linearize_std on (F,C,H,W) frames -> (lin float32, std float32 | None); every frame is its own batch.
+    ``layout`` "nhwc" / "nhwc_bgr": frames are (F,H,W,C); the outputs are planar (F,C,H,W)."""
     _check_stack(frames, "frames")
-    f, c, h, w = frames.shape
+    f = frames.shape[0]
+    c, h, w = _chw(frames, layout)
     dev = frames.device
     if std is not None:
         std_mode = "explicit"
@@ -157,11 +175,9 @@ def linearize_frames(frames: torch.Tensor, lut: torch.Tensor, interp: str = "lin
     if frames.dtype != torch.float32 and max_code is None:
         max_code = 255.0 if frames.dtype == torch.uint8 else 65535.0
     icrf, lut_keep = _icrf_struct(lut, interp, c)
-    geom = _geometry(frames, tile)
+    frames = frames.contiguous()
+    geom = _geometry(frames, tile, layout)
     lin = torch.empty((f, c, h, w), dtype=torch.float32, device=dev)
-    if lin.stride(0) != frames.stride(0):
-        frames = frames.contiguous()
-        geom = _geometry(frames, tile)
     std_out = torch.empty_like(lin) if want_std else None
     with torch.cuda.device(dev):
         rc = nv.load().ct_linearize_std(_ptr(frames), _DTYPE[frames.dtype], float(max_code or 1.0), f, ctypes.byref(geom),

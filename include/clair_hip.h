@@ -64,6 +64,14 @@ extern "C" {
 #define CT_MERGE_FINALIZE 2u     /* also write mean_out / std_out = sqrt(variance) after this batch */
 #define CT_MERGE_MEAN_OUT_F32 4u /* mean_out is float32 instead of the reference's float64 */
 
+/* Memory layout of one image of a stack.  Outputs and state are always planar (C, H, W) like the reference's tensors.
+ * NHWC = the interleaved layout OpenCV decodes to (clair_torch/common/data_io.py:125-154); NHWC_BGR additionally
+ * reverses the channel order on the fly, i.e. folds cv_to_torch (clair_torch/common/general_functions.py:315-335)
+ * into the load.  Supported by ct_hdr_merge_batch and ct_linearize_std; the other entry points take NCHW only. */
+#define CT_LAYOUT_NCHW 0
+#define CT_LAYOUT_NHWC 1
+#define CT_LAYOUT_NHWC_BGR 2
+
 /* Geometry of a (tile of a) stack. */
 typedef struct ct_geometry {
     int32_t channels;     /* C */
@@ -72,6 +80,7 @@ typedef struct ct_geometry {
     int64_t h_global;     /* rows of the full image (== h_tile when untiled) */
     int64_t row_offset;   /* first global row held locally */
     int64_t image_stride; /* elements between consecutive exposures / frames */
+    int32_t layout;       /* CT_LAYOUT_* of the INPUT stack */
 } ct_geometry;
 
 /* ICRF model: LUT (C, L) float32 row-major as ICRFModelBase._icrf (clair_torch/models/base.py:69-71). */

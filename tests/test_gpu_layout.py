@@ -1,0 +1,120 @@
+"""Raw OpenCV-layout ingest: interleaved (N,H,W,C) stacks, optionally BGR, read directly by the merge
+and linearize kernels.  The per-sample arithmetic and accumulation order are those of the planar path, so results must
+be bit-identical to the planar kernels on the transposed data (which are themselves pinned to the reference)."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from clair_torch_amd import _native
+    _native.load()
+    return torch.device("cuda:0")
+
+
+def _stack(rng, n, c, h, w, dtype):
+    hi = 256 if dtype == torch.uint8 else 65536
+    return torch.from_numpy(rng.integers(0, hi, size=(n, c, h, w)).astype(np.uint8 if dtype == torch.uint8 else np.uint16))
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.uint16])
+@pytest.mark.parametrize("shape", [(6, 3, 16, 24), (5, 3, 13, 7), (4, 1, 9, 11), (3, 4, 8, 8)])
+@pytest.mark.parametrize("mode", ["linear", "lookup", "catmull"])
+def test_merge_interleaved_equals_planar(dev, dtype, shape, mode):
+    from clair_torch_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    n, c, h, w = shape
+    planar = _stack(rng, n, c, h, w, dtype).to(dev)
+    t = torch.tensor([0.001 * 2.0 ** k for k in range(n)], dtype=torch.float64)
+    lut = torch.stack([torch.linspace(0, 1, 256) ** (1.8 + 0.3 * k) for k in range(c)]).to(dev)
+    kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+    mean_p, std_p = ops.hdr_merge_batch(planar, t, **kw)
+    nhwc = planar.permute(0, 2, 3, 1).contiguous()
+    mean_i, std_i = ops.hdr_merge_batch(nhwc, t, layout="nhwc", **kw)
+    assert mean_i.shape == (c, h, w) and torch.equal(mean_i, mean_p) and torch.equal(std_i, std_p)
+    bgr = planar.flip(1).permute(0, 2, 3, 1).contiguous()          # what cv2.imread would hand over
+    mean_b, std_b = ops.hdr_merge_batch(bgr, t, layout="nhwc_bgr", **kw)
+    assert torch.equal(mean_b, mean_p) and torch.equal(std_b, std_p)
+    # streaming state (two batches) and row-band tiles with the interleaved layout
+    st = ops.MergeState((c, h, w), dev, True)
+    ops.hdr_merge_batch(nhwc[:2], t[:2], state=st, finalize=False, layout="nhwc", **kw)
+    m2, s2 = ops.hdr_merge_batch(nhwc[2:], t[2:], state=st, finalize=True, layout="nhwc", **kw)
+    st_p = ops.MergeState((c, h, w), dev, True)
+    ops.hdr_merge_batch(planar[:2], t[:2], state=st_p, finalize=False, **kw)
+    m2p, s2p = ops.hdr_merge_batch(planar[2:], t[2:], state=st_p, finalize=True, **kw)
+    assert torch.equal(m2, m2p) and torch.equal(s2, s2p)
+    r0 = h // 3
+    band = nhwc[:, r0:].contiguous()
+    mt, stt = ops.hdr_merge_batch(band, t, layout="nhwc", tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw)
+    assert torch.equal(mt, mean_p[:, r0:]) and torch.equal(stt, std_p[:, r0:])
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.uint16])
+def test_linearize_interleaved_equals_planar(dev, dtype):
+    from clair_torch_amd import ops
+    rng = np.random.default_rng(3)
+    planar = _stack(rng, 4, 3, 19, 23, dtype).to(dev)
+    lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]).to(dev)
+    for mode in ("linear", "catmull"):
+        lin_p, sd_p = ops.linearize_frames(planar, lut, mode, std_mode="multiplier", std_value=0.05)
+        lin_i, sd_i = ops.linearize_frames(planar.flip(1).permute(0, 2, 3, 1).contiguous(), lut, mode,
+                                           std_mode="multiplier", std_value=0.05, layout="nhwc_bgr")
+        assert lin_i.shape == lin_p.shape and torch.equal(lin_i, lin_p) and torch.equal(sd_i, sd_p)
+
+
+def test_public_api_with_cv_to_torch_transform(dev):
+    """compute_hdr_image / linearize_dataset_generator fed raw (H,W,3) BGR uint16 frames with
+    gpu_transforms=[CvToTorch, CastTo, Normalize] (the reference's load_image chain) equal the planar RGB path, and a
+    non-fusable list (extra transform) still gives the same numbers through the generic route."""
+    from clair_torch_amd.common.enums import InterpMode, MissingStdMode
+    from clair_torch_amd.common.transforms import BaseTransform, CastTo, CvToTorch, Normalize
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.inference import compute_hdr_image, linearize_dataset_generator
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.training.losses import gaussian_value_weights
+    rng = np.random.default_rng(8)
+    planar = _stack(rng, 6, 3, 20, 28, torch.uint16)
+    raw = planar.flip(1).permute(0, 2, 3, 1).contiguous()
+    t = [0.002 * 2.0 ** k for k in range(6)]
+    model = ICRFModelDirect(icrf=torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]),
+                            interpolation_mode=InterpMode.LINEAR).to(dev)
+
+    class RawFrames(StackDataset):       # bypass StackDataset's (N,C,H,W) check: frames are (H,W,C) here
+        def __init__(self, frames, times):
+            self.values, self.stds, self.exposure_times = frames, None, times
+            self.files, self.std_hint = list(range(len(times))), ("multiplier", 0.05)
+            self.missing_std_mode, self.materialize_std = MissingStdMode.MULTIPLIER, False
+
+        def __len__(self):
+            return len(self.exposure_times)
+
+    norm = [CastTo("float32"), Normalize(65535, 0)]
+    ds_p = StackDataset(planar, t, missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05, materialize_std=False)
+    ref = compute_hdr_image(DataLoader(ds_p, batch_size=3, collate_fn=custom_collate), "cuda", model,
+                            weight_fn=gaussian_value_weights, gpu_transforms=norm)
+    got = compute_hdr_image(DataLoader(RawFrames(raw, t), batch_size=3, collate_fn=custom_collate), "cuda", model,
+                            weight_fn=gaussian_value_weights, gpu_transforms=[CvToTorch()] + norm)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+    class Identity(BaseTransform):
+        def __call__(self, x):
+            return x
+
+    slow = compute_hdr_image(DataLoader(RawFrames(raw, t), batch_size=3, collate_fn=custom_collate), "cuda", model,
+                             weight_fn=gaussian_value_weights, gpu_transforms=[CvToTorch(), Identity()] + norm)
+    # the generic route normalises with torch's own GPU division (x * (1/65535), as the reference itself would on a
+    # GPU), which is 1 ulp off the CPU reference for some codes and can flip the LUT interval at exact knots: the
+    # mean agrees to rounding, the std only norm-wise.  The fused route above is the bit-faithful one.
+    assert torch.allclose(slow[0], ref[0], rtol=1e-5)
+    assert float((slow[1] - ref[1]).norm() / ref[1].norm()) < 5e-3
+    lin_ref = list(linearize_dataset_generator(DataLoader(ds_p, batch_size=1, collate_fn=custom_collate), "cuda", model,
+                                               gpu_transforms=norm))
+    lin_got = list(linearize_dataset_generator(DataLoader(RawFrames(raw, t), batch_size=1, collate_fn=custom_collate),
+                                               "cuda", model, gpu_transforms=[CvToTorch()] + norm))
+    for a, b in zip(lin_got, lin_ref):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
