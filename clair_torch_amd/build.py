@@ -10,14 +10,16 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libclair_hip.so")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")   # per-source objects (git-ignored), so one edited kernel recompiles alone
 SOURCES = ["ct_merge.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_flatfield.hip", "ct_stats.hip", "ct_api.cpp"]
 HEADERS = ["ct_device.hpp", os.path.join("..", "..", "include", "clair_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
 
@@ -37,13 +39,34 @@ def is_stale():
     return any(os.path.getmtime(d) > built for d in deps)
 
 
+def _object_is_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    built = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > built for d in [src] + [os.path.join(CSRC, h) for h in HEADERS])
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library; returns its path."""
+    """Compile every HIP source (in parallel, one object each) and link them into one shared library."""
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH] + srcs
+    objs = [os.path.join(OBJ_DIR, os.path.basename(s) + ".o") for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if not force and not _object_is_stale(src, obj):
+            return
+        cmd = [hipcc] + FLAGS + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_one, zip(srcs, objs)))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -180,11 +180,12 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
     constexpr int kEntry = lut_entry_bytes(INTERP);
     const int C = a.channels, L = a.n_points;
     const int lut_bytes = C * L * kEntry;
-    float *hist = reinterpret_cast<float *>(lds + ((lut_bytes + 15) & ~15));
+    // float64 histogram: ds_add_f64 is ~10x cheaper than ds_add_f32 on gfx950 (tools/lds_atomic_rates.hip)
+    double *hist = reinterpret_cast<double *>(lds + ((lut_bytes + 15) & ~15));
     const bool want_lut = a.lut_grad != nullptr;
     stage_lut<INTERP>(lds, a.lut, C, L);
     if (want_lut)
-        for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist[k] = 0.0f;
+        for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist[k] = 0.0;
     __syncthreads();
     const float top = (float)(L - 1);
     const uint32_t stride = gridDim.x * (uint32_t)kBlock;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
         a.tile.locate(q, ch, qg);
         const int row = lut_row<INTERP>(qg, ch, C);
         const char *row_lds = lds + row * L * kEntry;
-        float *hrow = hist + row * L;
+        double *hrow = hist + row * L;
         for (uint32_t n = blockIdx.y; n < a.n_images; n += gridDim.y) {
             const int64_t off = (int64_t)n * a.image_stride + q;
             const float x = a.x[off], go = a.grad_out[off];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
                 if constexpr (INTERP == CT_INTERP_LOOKUP) {
                     float r = rintf(x * top);
                     r = fminf(fmaxf(r, 0.0f), top);
-                    atomicAdd(&hrow[(int)r], go);
+                    atomicAdd(&hrow[(int)r], (double)go);
                 } else {
                     const float s = fminf(fmaxf(x * top, 0.0f), top);
                     const float fl = floorf(s);
@@ -213,18 +214,18 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
                     const float t = s - fl;
                     if constexpr (INTERP == CT_INTERP_LINEAR) {
                         const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
-                        atomicAdd(&hrow[i0], go * (1.0f - t));
-                        atomicAdd(&hrow[i1], go * t);
+                        atomicAdd(&hrow[i0], (double)(go * (1.0f - t)));
+                        atomicAdd(&hrow[i1], (double)(go * t));
                     } else {
                         const float t2 = t * t, t3 = t2 * t;
                         const float w0 = -0.5f * t3 + t2 - 0.5f * t, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
                         const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * t, w3 = 0.5f * t3 - 0.5f * t2;
                         const int im = i0 > 0 ? i0 - 1 : 0, i1 = i0 + 1 < L ? i0 + 1 : L - 1,
                                   i2 = i0 + 2 < L ? i0 + 2 : L - 1;
-                        atomicAdd(&hrow[im], go * w0);
-                        atomicAdd(&hrow[i0], go * w1);
-                        atomicAdd(&hrow[i1], go * w2);
-                        atomicAdd(&hrow[i2], go * w3);
+                        atomicAdd(&hrow[im], (double)(go * w0));
+                        atomicAdd(&hrow[i0], (double)(go * w1));
+                        atomicAdd(&hrow[i1], (double)(go * w2));
+                        atomicAdd(&hrow[i2], (double)(go * w3));
                     }
                 }
             }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
     if (want_lut) {
         __syncthreads();
         for (int k = threadIdx.x; k < C * L; k += blockDim.x) {
-            const float v = hist[k];
+            const float v = (float)hist[k];
             if (v != 0.0f) atomicAdd(&a.lut_grad[k], v);
         }
     }
@@ -248,7 +249,7 @@ static int bwd_launch(const BwdArgs &a, hipStream_t s)
     if (gy > 8) gy = 8;
     if (gy < 1) gy = 1;
     const size_t lut_bytes = (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP);
-    const size_t lds = ((lut_bytes + 15) & ~(size_t)15) + sizeof(float) * (size_t)a.channels * a.n_points;
+    const size_t lds = ((lut_bytes + 15) & ~(size_t)15) + sizeof(double) * (size_t)a.channels * a.n_points;
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
     hipLaunchKernelGGL((linearize_bwd_kernel<INTERP>), dim3(gx, gy), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;

@@ -14,7 +14,7 @@
 //             (float32 inside a tile, float64 across tiles), one float64 atomic per sum per workgroup at the end.
 //   backward: wavefront <-> sample, lane <-> pixel; every lane sums dL/dI of its sample over the sample's partner
 //             list (uniform control flow, scalar pair data), then scatters into a (C, L) histogram in LDS
-//             (ds_add_f32 per tile, folded into a float64 LDS copy after every tile, flushed with float64 atomics).
+//             (ds_add_f64 -- far cheaper than ds_add_f32 on gfx950 --, flushed with float64 global atomics at the end).
 //
 // Arithmetic: the reference computes the residual in float64 because the ratio is float64.  Here
 // diff = I_i - I_j * r is formed with two float32 FMAs against r = r_hi + r_lo, which is exact to ~1 ulp of the
@@ -43,7 +43,9 @@ struct PairArgs {
     TileMap tile;
     uint32_t plane_local;
     int32_t n_images, n_pairs, channels, n_points;
-    int32_t tp;           // pixels per tile
+    int32_t tp;           // pixels per tile (power of two, divides the workgroup size)
+    int32_t tp_shift;     // log2(tp)
+    int32_t val_offset;   // backward: byte offset of the staged tile in LDS (after LUT, histograms, entries, splits)
     int32_t row_pitch;    // LDS row pitch in entries (tp + pad)
     int32_t pair_begin;   // first pair handled by this launch (forward)
     NormConst norm;
@@ -58,8 +60,11 @@ __device__ __forceinline__ float load_pixel(const void *base, int64_t idx, NormC
 }
 
 // Phase 1 shared by both kernels: linearize every sample of the tile into LDS.
-//   val[n*pitch + px] = (f(x), +-gauss(x))   sign = validity lo <= x <= hi
+//   val[n*pitch + px] = (f(x), gauss(x))   gauss = -inf when x is outside [lo, hi]: the pair weight g_i + g_j is then
+//                                          -inf as well and max(., 0) applies the pair mask in one instruction
 //   aux[n*pitch + px] = LUT coordinate s (backward) or linearized std |f'(x) sigma| (forward, STD != none)
+// The tile width is a power of two that divides the workgroup size (pick_tile), so a thread keeps one pixel column
+// for the whole tile and walks the samples: pixel index, global index and LUT row are computed once per tile.
 template <typename T, int INTERP, int STD, bool WANT_COORD>
 __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_lds, float2 *val, float *aux, int c,
                                            uint32_t pix0, int npix, float *aux2 = nullptr)
@@ -68,43 +73,64 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
     constexpr int kEntry = lut_entry_bytes(INTERP);
     const int N = a.n_images, L = a.n_points;
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
-    const int total = N * a.tp;
-    for (int k = threadIdx.x; k < total; k += blockDim.x) {
-        const int n = k / a.tp, px = k - n * a.tp;
-        float2 v = make_float2(0.0f, -1.0f);
-        float ax = 0.0f, ax2 = 0.0f;
-        if (px < npix) {
-            const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + px;
-            const int64_t off = (int64_t)n * a.image_stride + ql;
-            const float x = load_pixel<T>(a.stack, off, a.norm);
-            int ch;
-            uint32_t qg;
-            a.tile.locate(ql, ch, qg);
-            const char *row = lut_lds + lut_row<INTERP>(qg, ch, a.channels) * L * kEntry;
-            float dfdx;
-            const float lin = icrf_sample<INTERP, true, kRanged>(x, row, top, dfdx);
-            const float d = x - 0.5f;
-            const float gw = __builtin_amdgcn_exp2f((d * d) * a.neg_scale_log2e);
-            const bool valid = x >= a.lower && x <= a.upper;
-            v = make_float2(lin, valid ? gw : -gw);
-            float lsd = 0.0f;
-            if constexpr (STD != CT_STD_NONE) {
-                float sigma = a.std_value;
-                if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;
-                if constexpr (STD == CT_STD_EXPLICIT) sigma = a.std_stack[off];
-                lsd = fabsf(dfdx * sigma);  // icrf_training.py:117-126: |grads * stds|
-            }
-            if constexpr (WANT_COORD) {
-                ax = fminf(fmaxf(x * top, 0.0f), top);
-                ax2 = lsd;
-            } else {
-                ax = lsd;
-            }
+    const int px = (int)threadIdx.x & (a.tp - 1);
+    const int n0 = (int)threadIdx.x >> a.tp_shift, nstep = (int)blockDim.x >> a.tp_shift;
+    const bool inb = px < npix;
+    const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + (uint32_t)px;
+    const uint32_t qg = ql + (uint32_t)c * a.tile.chan_skip + a.tile.base;  // TileMap::locate with the channel known
+    const char *row = lut_lds + (inb ? lut_row<INTERP>(qg, c, a.channels) : 0) * L * kEntry;
+    // samples are walked in batches of kBatch with all of a batch's HBM loads issued before the first is used
+    constexpr int kBatch = 4;
+    const T *src = static_cast<const T *>(a.stack) + ql;
+    for (int nb = n0; nb < N; nb += kBatch * nstep) {
+        T raw[kBatch];
+        float sraw[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int n = nb + k * nstep;
+            const bool live = inb && n < N;
+            raw[k] = live ? src[(int64_t)n * a.image_stride] : T(0);
+            if constexpr (STD == CT_STD_EXPLICIT) sraw[k] = live ? a.std_stack[(int64_t)n * a.image_stride + ql] : 0.0f;
         }
-        val[n * a.row_pitch + px] = v;
-        if constexpr (WANT_COORD || STD != CT_STD_NONE) aux[n * a.row_pitch + px] = ax;
-        if constexpr (WANT_COORD && STD != CT_STD_NONE) aux2[n * a.row_pitch + px] = ax2;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int n = nb + k * nstep;
+            if (n >= N) break;
+            float2 v = make_float2(0.0f, -INFINITY);
+            float ax = 0.0f, ax2 = 0.0f;
+            if (inb) {
+                const float x = to_pixel<T>(raw[k], a.norm);
+                float dfdx;
+                const float lin = icrf_sample<INTERP, true, kRanged>(x, row, top, dfdx);
+                const float d = x - 0.5f;
+                const float gw = __builtin_amdgcn_exp2f((d * d) * a.neg_scale_log2e);
+                const bool valid = x >= a.lower && x <= a.upper;
+                v = make_float2(lin, valid ? gw : -INFINITY);
+                float lsd = 0.0f;
+                if constexpr (STD != CT_STD_NONE) {
+                    float sigma = a.std_value;
+                    if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;
+                    if constexpr (STD == CT_STD_EXPLICIT) sigma = sraw[k];
+                    lsd = fabsf(dfdx * sigma);  // icrf_training.py:117-126: |grads * stds|
+                }
+                if constexpr (WANT_COORD) {
+                    ax = fminf(fmaxf(x * top, 0.0f), top);
+                    ax2 = lsd;
+                } else {
+                    ax = lsd;
+                }
+            }
+            val[n * a.row_pitch + px] = v;
+            if constexpr (WANT_COORD || STD != CT_STD_NONE) aux[n * a.row_pitch + px] = ax;
+            if constexpr (WANT_COORD && STD != CT_STD_NONE) aux2[n * a.row_pitch + px] = ax2;
+        }
     }
+}
+
+// sign(d) in {-1, 0, +1} without compares: d * 2^127 is >= 2 in magnitude for every normal d, the median clamps it.
+__device__ __forceinline__ float sign_of(float d)
+{
+    return __builtin_amdgcn_fmed3f(d * 0x1p127f, -1.0f, 1.0f);
 }
 
 // ---- forward -------------------------------------------------------------------------------------
@@ -169,15 +195,14 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
             for (int px = 0; px < npix; ++px) {
                 const float2 A = vi[px], Bv = vj[px];
                 // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
-                const float e = Bv.x * rhi[s];
                 const float d1 = __builtin_fmaf(-Bv.x, rhi[s], A.x);
                 float diff = __builtin_fmaf(-Bv.x, rlo[s], d1);
-                const float es = e + 1e-6f;
-                const float inv_es = __builtin_amdgcn_rcpf(es);
-                if constexpr (REL) diff *= inv_es;
-                const float v = fabsf(diff);
-                const bool m = fminf(A.y, Bv.y) > 0.0f;  // both samples inside [lower, upper]
-                float wt = fabsf(A.y) + fabsf(Bv.y);      // Gaussian pair weight (losses.py:231-234)
+                float inv_es = 0.0f;  // 1 / (expected + 1e-6), losses.py:45-47
+                if constexpr (REL) {
+                    inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Bv.x, rhi[s], 1e-6f));
+                    diff *= inv_es;
+                }
+                float wt = A.y + Bv.y;  // Gaussian pair weight (losses.py:231-234); -inf unless both samples are valid
                 float err = 0.0f;
                 if constexpr (STD != CT_STD_NONE) {
                     const float si = xi[px], sj = xj[px];
@@ -192,11 +217,12 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
                     }
                     if (a.use_unc_weight) wt += __builtin_amdgcn_rcpf(err + 1e-6f);  // losses.py:96
                 }
-                const float wm = m ? wt : 0.0f;
+                const float wm = fmaxf(wt, 0.0f);
                 f[0] += wm;
-                f[1] = __builtin_fmaf(v, wm, f[1]);
+                f[1] = __builtin_fmaf(fabsf(diff), wm, f[1]);
                 if constexpr (LEVEL == 1) {
-                    const float dvc = v - cen[s];
+                    const bool m = wt >= 0.0f;
+                    const float dvc = fabsf(diff) - cen[s];
                     f[2] = __builtin_fmaf(dvc * dvc, wm, f[2]);
                     f[3] += m ? err : 0.0f;
                     f[4] += m ? 1.0f : 0.0f;
@@ -223,10 +249,10 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
 // One partner-list entry, resolved once per workgroup into LDS so the inner loop has no dependent scalar loads:
 // partner sample's LDS row, which side of the pair this sample is on, the ratio split in two floats, and the
 // upstream coefficient of that pair for this workgroup's channel.
-struct PartnerEntry {
-    int row;    // partner sample * row_pitch, bit 31 set when the OWN sample is the pair's second image (j)
-    float rhi, rlo, cf;
-    float sm;   // spatial mean of the pair (only read by the uncertainty-weighted backward)
+struct PartnerEntry {  // 16 bytes: one broadcast ds_read_b128 per partner
+    int row;    // partner sample's row in the staged tile, as a BYTE offset into val[] (row * row_pitch * 8)
+    float rhi, rlo;  // exposure ratio split in two floats
+    float cf;   // upstream coefficient; without uncertainty weighting the side's constant factor is folded in
 };
 
 // Design note (measured, C3 shape): evaluating every pair ONCE (own-side gradient in a register, partner-side via
@@ -235,45 +261,113 @@ struct PartnerEntry {
 // VALU work but keeps the inner loop free of LDS writes.
 // 512 threads (8 waves) per workgroup: at N = 64 the staged tile + partner entries take ~90 KB of LDS, so only one
 // workgroup fits a CU; eight waves keep two per SIMD to cover the LDS latency of the partner loop.
-constexpr int kBwdBlock = 512;
+constexpr int kBwdBlock = 1024;
+
+// dL/dI_own contribution of one partner entry (lane = pixel).  OWN_IS_I: the own sample is the pair's first image.
+//   v = |q|, q = (I_i - r I_j) / (r I_j + eps)  [REL]  or  q = I_i - r I_j:
+//   dq/dI_i = 1/es,  dq/dI_j = -r (I_i + eps)/es^2   [REL];   dq/dI_i = 1, dq/dI_j = -r   [absolute]
+// and dv = sign(q) dq.  Without uncertainty weighting the entry's cf already carries the side's constant factor
+// (cf for i, -cf r for j), the mask comes from the -inf encoded weight, and sign(q)/es is sign(diff)/|es|.
+template <bool REL, bool UNC, bool OWN_IS_I>
+__device__ __forceinline__ void partner_term(float &G, const PartnerEntry &pe, float sm, float2 own, float own_sd,
+                                             float2 oth, float oth_sd)
+{
+    const float Ii = OWN_IS_I ? own.x : oth.x, Ij = OWN_IS_I ? oth.x : own.x;
+    const float d1 = __builtin_fmaf(-Ij, pe.rhi, Ii);
+    const float diff = __builtin_fmaf(-Ij, pe.rlo, d1);
+    const float ws = own.y + oth.y;  // Gaussian pair weight, -inf unless both samples are valid
+    if constexpr (!UNC) {
+        const float wm = fmaxf(ws, 0.0f);
+        const float sg = sign_of(diff);
+        if constexpr (REL) {
+            const float inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Ij, pe.rhi, 1e-6f));
+            float t = wm * fabsf(inv_es);
+            if constexpr (!OWN_IS_I) t *= (Ii + 1e-6f) * inv_es;
+            G = __builtin_fmaf(pe.cf, t * sg, G);
+        } else {
+            G = __builtin_fmaf(pe.cf, wm * sg, G);
+        }
+    } else {
+        const bool mk = ws >= 0.0f;
+        float wt = fmaxf(ws, 0.0f), dv, extra = 0.0f;  // extra = (v - mean) dw/dI_own; finite even when masked
+        const float si = OWN_IS_I ? own_sd : oth_sd, sj = OWN_IS_I ? oth_sd : own_sd;
+        if constexpr (REL) {
+            const float inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Ij, pe.rhi, 1e-6f));
+            const float q = diff * inv_es;
+            const float sg = sign_of(q);
+            dv = OWN_IS_I ? sg * inv_es : -sg * pe.rhi * (Ii + 1e-6f) * inv_es * inv_es;
+            const float inv_ijs = __builtin_amdgcn_rcpf(fmaxf(Ij, 1e-6f));
+            const float t1 = si * inv_es, t2 = (Ii * sj) * inv_es * inv_ijs;  // losses.py:55-57
+            const float err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
+            const float uw = __builtin_amdgcn_rcpf(err + 1e-6f);
+            wt += uw;
+            float derr;
+            if constexpr (OWN_IS_I)  // d err / d I_i: only t2 depends on I_i
+                derr = t2 * (sj * inv_es * inv_ijs);
+            else  // d err / d I_j: both terms through (e + eps), t2 also through clamp(I_j, eps)
+                derr = -(t1 * t1 * pe.rhi * inv_es + t2 * t2 * (pe.rhi * inv_es + (Ij >= 1e-6f ? inv_ijs : 0.0f)));
+            derr *= __builtin_amdgcn_rcpf(err);
+            extra = (fabsf(q) - sm) * (-uw * uw * derr);
+        } else {  // losses.py:61: the error does not depend on the LUT
+            const float sg = sign_of(diff);
+            dv = OWN_IS_I ? sg : -sg * pe.rhi;
+            const float rs = pe.rhi * sj;
+            wt += __builtin_amdgcn_rcpf(sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
+        }
+        G = __builtin_fmaf(mk ? pe.cf : 0.0f, __builtin_fmaf(wt, dv, extra), G);
+    }
+}
 
 // STD != CT_STD_NONE selects the uncertainty-weighted loss (weights w = 1/(err + 1e-6) + gauss, losses.py:93-100),
 // whose weights depend on the LUT through err when the loss is relative:  d mean = sum m [w dv + (v - mean) dw] / D.
-template <typename T, int INTERP, bool REL, int STD>
+// PPL = pixels per lane (tile = 64 * PPL pixels): with two, one partner entry serves two evaluations.
+template <typename T, int INTERP, bool REL, int STD, int PPL>
 __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
 {
     extern __shared__ __align__(16) char lds[];
     constexpr int kEntry = lut_entry_bytes(INTERP);
     const int C = a.channels, L = a.n_points, N = a.n_images;
     const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
+    // (C, L) float64 histogram: ds_add_f64 costs ~20 cycles per wave-instruction on random bins where ds_add_f32 costs
+    // ~190 on ANY address pattern (tools/lds_atomic_rates.hip), so the gradient is scattered in float64 directly.
     double *hist64 = reinterpret_cast<double *>(lds + lut_bytes);
-    float *hist32 = reinterpret_cast<float *>(hist64 + C * L);
-    PartnerEntry *ent = reinterpret_cast<PartnerEntry *>(hist32 + ((C * L + 3) & ~3));
+    PartnerEntry *ent = reinterpret_cast<PartnerEntry *>(hist64 + C * L);
     const int n_ent = 2 * a.n_pairs;
-    float2 *val = reinterpret_cast<float2 *>(ent + n_ent);
+    float2 *val = reinterpret_cast<float2 *>(lds + a.val_offset);
     float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
     float *lsdv = aux + (size_t)N * a.row_pitch;  // linearized std per sample (STD != none only)
     constexpr bool kUnc = STD != CT_STD_NONE;
     const int c = blockIdx.x % C;
     stage_lut<INTERP>(lds, a.lut, C, L);
-    for (int k = threadIdx.x; k < C * L; k += blockDim.x) {
-        hist64[k] = 0.0;
-        hist32[k] = 0.0f;
+    for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
+    // Partner entries, each sample's list stably partitioned into "own sample is i" entries followed by "own sample
+    // is j" entries (split[n] = first j-side entry), so the pixel loop runs two select-free loops per sample.
+    float *smv = reinterpret_cast<float *>(ent + n_ent);  // spatial mean per entry (uncertainty-weighted backward)
+    int *split = reinterpret_cast<int *>(smv + (kUnc ? n_ent : 0));
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int e0 = a.part_off[n], e1 = a.part_off[n + 1];
+        int n_i = 0;
+        for (int e = e0; e < e1; ++e) n_i += a.part_pair[e] >= 0 ? 1 : 0;
+        split[n] = e0 + n_i;
+        int at_i = e0, at_j = e0 + n_i;
+        for (int e = e0; e < e1; ++e) {
+            const int code = a.part_pair[e];
+            const bool own_is_i = code >= 0;
+            const int p = own_is_i ? code : ~code;
+            const double r = a.ratio[p];
+            PartnerEntry pe;
+            pe.row = a.part_sample[e] * a.row_pitch * (int)sizeof(float2);
+            pe.rhi = (float)r;
+            pe.rlo = (float)(r - (double)pe.rhi);
+            const float cf = (float)a.coef[(int64_t)p * C + c];
+            pe.cf = (kUnc || own_is_i) ? cf : -cf * pe.rhi;
+            const int at = own_is_i ? at_i++ : at_j++;
+            ent[at] = pe;
+            if constexpr (kUnc) smv[at] = (float)a.smean[(int64_t)p * C + c];
+        }
     }
-    for (int e = threadIdx.x; e < n_ent; e += blockDim.x) {
-        const int code = a.part_pair[e];
-        const bool own_is_i = code >= 0;
-        const int p = own_is_i ? code : ~code;
-        const double r = a.ratio[p];
-        PartnerEntry pe;
-        pe.row = (a.part_sample[e] * a.row_pitch) | (own_is_i ? 0 : (int)0x80000000);
-        pe.rhi = (float)r;
-        pe.rlo = (float)(r - (double)pe.rhi);
-        pe.cf = (float)a.coef[(int64_t)p * C + c];
-        pe.sm = kUnc ? (float)a.smean[(int64_t)p * C + c] : 0.0f;
-        ent[e] = pe;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // the wavefront index is uniform: readfirstlane lets the sample / partner loops run on the scalar unit
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
     for (uint32_t t = blockIdx.x / C; t < tiles; t += gstep) {
@@ -282,95 +376,80 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
         __syncthreads();
         stage_tile<T, INTERP, STD, true>(a, lds, val, aux, c, pix0, npix, lsdv);
         __syncthreads();
-        for (int px = lane; px < a.tp; px += 64) {
-            const bool inb = px < npix;
-            int ch = c;
-            uint32_t qg = 0;
-            if (inb) a.tile.locate((uint32_t)c * a.plane_local + pix0 + px, ch, qg);
-            float *hrow = hist32 + lut_row<INTERP>(qg, ch, C) * L;
-            for (int n = wave; n < N; n += nwaves) {
-                const float2 own = val[n * a.row_pitch + px];
-                const float own_sd = kUnc ? lsdv[n * a.row_pitch + px] : 0.0f;
-                float G = 0.0f;
-                const int e0 = a.part_off[n], e1 = a.part_off[n + 1];
+        const int col = min(lane, a.tp - 1);  // 32-pixel tiles (very large N): the upper half-wave idles in bounds
+        const char *valb = reinterpret_cast<const char *>(val + col);
+        const char *lsdb = reinterpret_cast<const char *>(lsdv + col);
+        for (int n = wave; n < N; n += nwaves) {
+            float2 own[PPL];
+            float own_sd[PPL], G[PPL];
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                own[k] = val[n * a.row_pitch + col + 64 * k];
+                own_sd[k] = kUnc ? lsdv[n * a.row_pitch + col + 64 * k] : 0.0f;
+                G[k] = 0.0f;
+            }
+#ifdef CT_DBG_SKIP_PAIRS
+            const int e0 = 0, em = 0, e1 = 0;
+#else
+            const int e0 = a.part_off[n], em = __builtin_amdgcn_readfirstlane(split[n]), e1 = a.part_off[n + 1];
+#endif
 #pragma unroll 4
-                for (int e = e0; e < e1; ++e) {
-                    const PartnerEntry pe = ent[e];
-                    const bool own_is_i = pe.row >= 0;
-                    const float2 oth = val[(pe.row & 0x7fffffff) + px];
-                    const float Ii = own_is_i ? own.x : oth.x, Ij = own_is_i ? oth.x : own.x;
-                    const float ev = Ij * pe.rhi;
-                    const float d1 = __builtin_fmaf(-Ij, pe.rhi, Ii);
-                    const float diff = __builtin_fmaf(-Ij, pe.rlo, d1);
-                    const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
-                    const bool mk = fminf(own.y, oth.y) > 0.0f;
-                    float wt = fabsf(own.y) + fabsf(oth.y);
-                    float dv, extra = 0.0f;  // extra = (v - mean) dw/dI_own
-                    if constexpr (REL) {
-                        const float inv_es = __builtin_amdgcn_rcpf(ev + 1e-6f);
-                        // v = |(I_i - e)/(e + eps)|: dv/dI_i = sgn/(e+eps); dv/dI_j = -sgn r (I_i + eps)/(e+eps)^2
-                        dv = own_is_i ? sgn * inv_es : -sgn * pe.rhi * (Ii + 1e-6f) * inv_es * inv_es;
-                        if constexpr (kUnc) {
-                            const float oth_sd = lsdv[(pe.row & 0x7fffffff) + px];
-                            const float si = own_is_i ? own_sd : oth_sd, sj = own_is_i ? oth_sd : own_sd;
-                            const float inv_ijs = __builtin_amdgcn_rcpf(fmaxf(Ij, 1e-6f));
-                            const float t1 = si * inv_es, t2 = (Ii * sj) * inv_es * inv_ijs;  // losses.py:55-57
-                            const float err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
-                            const float uw = __builtin_amdgcn_rcpf(err + 1e-6f);
-                            wt += uw;
-                            float derr;
-                            if (own_is_i)  // d err / d I_i: only t2 depends on I_i
-                                derr = t2 * (sj * inv_es * inv_ijs);
-                            else  // d err / d I_j: both terms through (e + eps), t2 also through clamp(I_j, eps)
-                                derr = -(t1 * t1 * pe.rhi * inv_es +
-                                         t2 * t2 * (pe.rhi * inv_es + (Ij >= 1e-6f ? inv_ijs : 0.0f)));
-                            derr *= __builtin_amdgcn_rcpf(err);
-                            extra = (fabsf(diff * inv_es) - pe.sm) * (-uw * uw * derr);
-                        }
-                    } else {
-                        dv = own_is_i ? sgn : -sgn * pe.rhi;
-                        if constexpr (kUnc) {  // losses.py:61: the error does not depend on the LUT
-                            const float oth_sd = lsdv[(pe.row & 0x7fffffff) + px];
-                            const float si = own_is_i ? own_sd : oth_sd, sj = own_is_i ? oth_sd : own_sd;
-                            const float rs = pe.rhi * sj;
-                            wt += __builtin_amdgcn_rcpf(sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
-                        }
-                    }
-                    G = __builtin_fmaf(mk ? pe.cf : 0.0f, __builtin_fmaf(wt, dv, extra), G);
+            for (int e = e0; e < em; ++e) {
+                const PartnerEntry pe = ent[e];
+                const float sm = kUnc ? smv[e] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const float2 oth = *reinterpret_cast<const float2 *>(valb + pe.row + 512 * k);
+                    const float oth_sd = kUnc ? *reinterpret_cast<const float *>(lsdb + (pe.row >> 1) + 256 * k) : 0.0f;
+                    partner_term<REL, kUnc, true>(G[k], pe, sm, own[k], own_sd[k], oth, oth_sd);
                 }
-                if (inb && G != 0.0f) {
+            }
+#pragma unroll 4
+            for (int e = em; e < e1; ++e) {
+                const PartnerEntry pe = ent[e];
+                const float sm = kUnc ? smv[e] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) {
+                    const float2 oth = *reinterpret_cast<const float2 *>(valb + pe.row + 512 * k);
+                    const float oth_sd = kUnc ? *reinterpret_cast<const float *>(lsdb + (pe.row >> 1) + 256 * k) : 0.0f;
+                    partner_term<REL, kUnc, false>(G[k], pe, sm, own[k], own_sd[k], oth, oth_sd);
+                }
+            }
+#ifdef CT_DBG_SKIP_SCATTER
+            if (G[0] == 123.0f) hist64[0] = G[PPL - 1];
+            continue;
+#endif
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const int px = lane + 64 * k;
+                if (px < npix && G[k] != 0.0f) {
+                    const uint32_t qg = (uint32_t)c * (a.plane_local + a.tile.chan_skip) + a.tile.base + pix0 + (uint32_t)px;
+                    double *hrow = hist64 + lut_row<INTERP>(qg, c, C) * L;
                     const float s = aux[n * a.row_pitch + px];
+                    const float Gk = G[k];
                     if constexpr (INTERP == CT_INTERP_LOOKUP) {
-                        atomicAdd(&hrow[(int)rintf(s)], G);
+                        atomicAdd(&hrow[(int)rintf(s)], (double)Gk);
                     } else {
                         const float fl = floorf(s);
                         const int i0 = (int)fl;
                         const float tt = s - fl;
                         if constexpr (INTERP == CT_INTERP_LINEAR) {
                             const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
-                            atomicAdd(&hrow[i0], G * (1.0f - tt));
-                            atomicAdd(&hrow[i1], G * tt);
+                            atomicAdd(&hrow[i0], (double)(Gk * (1.0f - tt)));
+                            atomicAdd(&hrow[i1], (double)(Gk * tt));
                         } else {
                             const float t2 = tt * tt, t3 = t2 * tt;
                             const float w0 = -0.5f * t3 + t2 - 0.5f * tt, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
                             const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * tt, w3 = 0.5f * t3 - 0.5f * t2;
                             const int im = i0 > 0 ? i0 - 1 : 0, i1 = i0 + 1 < L ? i0 + 1 : L - 1,
                                       i2 = i0 + 2 < L ? i0 + 2 : L - 1;
-                            atomicAdd(&hrow[im], G * w0);
-                            atomicAdd(&hrow[i0], G * w1);
-                            atomicAdd(&hrow[i1], G * w2);
-                            atomicAdd(&hrow[i2], G * w3);
+                            atomicAdd(&hrow[im], (double)(Gk * w0));
+                            atomicAdd(&hrow[i0], (double)(Gk * w1));
+                            atomicAdd(&hrow[i1], (double)(Gk * w2));
+                            atomicAdd(&hrow[i2], (double)(Gk * w3));
                         }
                     }
                 }
-            }
-        }
-        __syncthreads();
-        for (int k = threadIdx.x; k < C * L; k += blockDim.x) {
-            const float h = hist32[k];
-            if (h != 0.0f) {
-                hist64[k] += (double)h;
-                hist32[k] = 0.0f;
             }
         }
     }
@@ -382,9 +461,9 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
 // ---- host side -------------------------------------------------------------------------------------
 static int pick_tile(int n_images, size_t fixed_bytes, int bytes_per_entry, int want)
 {
-    // largest tile (multiple of 32, <= want) whose staging fits beside the fixed LDS part in ~144 KiB
+    // largest tile (power of two, 32 <= tp <= want) whose staging fits beside the fixed LDS part in ~144 KiB
     const size_t budget = 144 * 1024;
-    for (int tp = want; tp >= 32; tp -= 32) {
+    for (int tp = want; tp >= 32; tp /= 2) {
         const size_t need = fixed_bytes + (size_t)n_images * (tp + 1) * bytes_per_entry;
         if (need <= budget) return tp;
     }
@@ -417,6 +496,7 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
     const int tp = pick_tile(a.n_images, lut_bytes, entry, 64);
     if (tp == 0) return CT_ERR_TOO_LARGE;
     a.tp = tp;
+    a.tp_shift = tp == 64 ? 6 : 5;
     a.row_pitch = tp + 1;
     const size_t lds = lut_bytes + (size_t)a.n_images * a.row_pitch * entry;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
@@ -438,9 +518,13 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
     return CT_OK;
 }
 
+// CT_PAIRS_MINIMAL (tools/pairs_bench.hip only): instantiate just uint16 / LINEAR / no std so the harness builds fast.
 template <typename T, int INTERP>
 static int fwd_dispatch_std(const PairArgs &a, int std_mode, int level, hipStream_t s)
 {
+#ifdef CT_PAIRS_MINIMAL
+    return std_mode == CT_STD_NONE ? fwd_launch<T, INTERP, CT_STD_NONE>(a, level, s) : CT_ERR_UNSUPPORTED;
+#endif
     switch (std_mode) {
         case CT_STD_NONE: return fwd_launch<T, INTERP, CT_STD_NONE>(a, level, s);
         case CT_STD_CONSTANT: return fwd_launch<T, INTERP, CT_STD_CONSTANT>(a, level, s);
@@ -453,6 +537,9 @@ static int fwd_dispatch_std(const PairArgs &a, int std_mode, int level, hipStrea
 template <typename T>
 static int fwd_dispatch(const PairArgs &a, int interp, int std_mode, int level, hipStream_t s)
 {
+#ifdef CT_PAIRS_MINIMAL
+    return interp == CT_INTERP_LINEAR ? fwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, level, s) : CT_ERR_UNSUPPORTED;
+#endif
     switch (interp) {
         case CT_INTERP_LOOKUP: return fwd_dispatch_std<T, CT_INTERP_LOOKUP>(a, std_mode, level, s);
         case CT_INTERP_LINEAR: return fwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, level, s);
@@ -467,26 +554,41 @@ static int bwd_launch_pairs(PairArgs a, hipStream_t s)
 {
     const size_t lut_bytes = ((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15;
     const size_t cl = (size_t)a.channels * a.n_points;
-    const size_t fixed = lut_bytes + cl * 8 + ((cl + 3) & ~(size_t)3) * 4 + (size_t)2 * a.n_pairs * sizeof(PartnerEntry);
+    // LUT | float64 histogram | partner entries [| spatial means] | per-sample split | staged tile
+    const size_t per_entry = sizeof(PartnerEntry) + (STD == CT_STD_NONE ? 0 : 4);
+    const size_t fixed = (lut_bytes + cl * 8 + (size_t)2 * a.n_pairs * per_entry +
+                          (size_t)a.n_images * 4 + 15) & ~(size_t)15;
     const int per_sample = STD == CT_STD_NONE ? 12 : 16;
-    const int tp = pick_tile(a.n_images, fixed, per_sample, 64);
+    const int tp = pick_tile(a.n_images, fixed, per_sample, 128);
     if (tp == 0) return CT_ERR_TOO_LARGE;
     a.tp = tp;
+    a.tp_shift = tp == 128 ? 7 : (tp == 64 ? 6 : 5);
+    a.val_offset = (int32_t)fixed;
     a.row_pitch = tp + 1;
     const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
     int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
     const int grid = per_chan * a.channels;
-    if (a.use_relative)
-        hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, true, STD>), dim3(grid), dim3(kBwdBlock), lds, s, a);
-    else
-        hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, false, STD>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+    if (tp == 128) {
+        if (a.use_relative)
+            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, true, STD, 2>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+        else
+            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, false, STD, 2>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+    } else {
+        if (a.use_relative)
+            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, true, STD, 1>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+        else
+            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, false, STD, 1>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+    }
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
 template <typename T, int INTERP>
 static int bwd_dispatch_std(const PairArgs &a, int std_mode, hipStream_t s)
 {
+#ifdef CT_PAIRS_MINIMAL
+    return std_mode == CT_STD_NONE ? bwd_launch_pairs<T, INTERP, CT_STD_NONE>(a, s) : CT_ERR_UNSUPPORTED;
+#endif
     switch (std_mode) {
         case CT_STD_NONE: return bwd_launch_pairs<T, INTERP, CT_STD_NONE>(a, s);
         case CT_STD_CONSTANT: return bwd_launch_pairs<T, INTERP, CT_STD_CONSTANT>(a, s);
@@ -499,6 +601,9 @@ static int bwd_dispatch_std(const PairArgs &a, int std_mode, hipStream_t s)
 template <typename T>
 static int bwd_dispatch(const PairArgs &a, int interp, int std_mode, hipStream_t s)
 {
+#ifdef CT_PAIRS_MINIMAL
+    return interp == CT_INTERP_LINEAR ? bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, s) : CT_ERR_UNSUPPORTED;
+#endif
     switch (interp) {
         case CT_INTERP_LOOKUP: return bwd_dispatch_std<T, CT_INTERP_LOOKUP>(a, std_mode, s);
         case CT_INTERP_LINEAR: return bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, s);
@@ -570,13 +675,15 @@ extern "C" int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float 
     a.center = center_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
+#ifndef CT_PAIRS_MINIMAL
         case CT_DTYPE_U8:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
             return fwd_dispatch<uint8_t>(a, icrf->interp, params->std_mode, level, s);
+        case CT_DTYPE_F32: return fwd_dispatch<float>(a, icrf->interp, params->std_mode, level, s);
+#endif
         case CT_DTYPE_U16:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
             return fwd_dispatch<uint16_t>(a, icrf->interp, params->std_mode, level, s);
-        case CT_DTYPE_F32: return fwd_dispatch<float>(a, icrf->interp, params->std_mode, level, s);
     }
     return CT_ERR_UNSUPPORTED;
 }
@@ -613,13 +720,15 @@ extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float 
     a.lut_grad = lut_grad_dev;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (dtype) {
+#ifndef CT_PAIRS_MINIMAL
         case CT_DTYPE_U8:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
             return bwd_dispatch<uint8_t>(a, icrf->interp, prm.std_mode, s);
+        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, prm.std_mode, s);
+#endif
         case CT_DTYPE_U16:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
             return bwd_dispatch<uint16_t>(a, icrf->interp, prm.std_mode, s);
-        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, prm.std_mode, s);
     }
     return CT_ERR_UNSUPPORTED;
 }
