@@ -18,8 +18,9 @@ LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BGR = 0, 1, 2
 MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32 = 1, 2, 4
 ERR_NO_GRADIENT_PATH = -4
 
+ABI_VERSION = 2
 EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd",
-           "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_flatfield_sums",
+           "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_pair_residual_bwd_workspace", "ct_flatfield_sums",
            "ct_flatfield_apply", "ct_video_stats_batch")
 
 
@@ -79,15 +80,18 @@ def load():
         lib.ct_pair_residual_fwd.restype = i32
         lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, i32, vp, vp, vp]
         lib.ct_pair_residual_bwd.restype = i32
-        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp, vp]
+        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp, vp, i64,
+                                             vp]
+        lib.ct_pair_residual_bwd_workspace.restype = i64
+        lib.ct_pair_residual_bwd_workspace.argtypes = [i32, i32, i32]
     lib.ct_flatfield_sums.restype = i32
     lib.ct_flatfield_sums.argtypes = [vp, i32, vp, i32, i64, vp, vp]
     lib.ct_flatfield_apply.restype = i32
     lib.ct_flatfield_apply.argtypes = [vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i64, vp]
     lib.ct_video_stats_batch.restype = i32
     lib.ct_video_stats_batch.argtypes = [vp, i32, f32, i32, gp, ip, f32, vp, vp, vp]
-    if lib.ct_abi_version() != 1:
-        raise NativeLibraryError(f"{path}: ABI version {lib.ct_abi_version()} != 1; rebuild the library")
+    if lib.ct_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"{path}: ABI version {lib.ct_abi_version()} != {ABI_VERSION}; rebuild the library")
     _lib = lib
     return lib
 

@@ -39,12 +39,15 @@ struct PairArgs {
     const double *coef;                                 // (P, C)
     const double *smean;                                // (P, C) spatial means (uncertainty-weighted backward)
     double *lut_grad;                                   // (C, L) float64, +=
+    const int32_t *first_g;                             // workspace: N + 1 offsets of the i-side entries per sample
+    const void *table_g;                                // workspace: (C, P) PartnerEntry, grouped by sample i
     int64_t image_stride;
     TileMap tile;
     uint32_t plane_local;
     int32_t n_images, n_pairs, channels, n_points;
     int32_t tp;           // pixels per tile (power of two, divides the workgroup size)
     int32_t tp_shift;     // log2(tp)
+    int32_t vec;          // 1: planes are 4-element aligned -> vectorised, prefetching staging with permuted columns
     int32_t val_offset;   // backward: byte offset of the staged tile in LDS (after LUT, histograms, entries, splits)
     int32_t row_pitch;    // LDS row pitch in entries (tp + pad)
     int32_t pair_begin;   // first pair handled by this launch (forward)
@@ -67,14 +70,14 @@ __device__ __forceinline__ float load_pixel(const void *base, int64_t idx, NormC
 // for the whole tile and walks the samples: pixel index, global index and LUT row are computed once per tile.
 template <typename T, int INTERP, int STD, bool WANT_COORD>
 __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_lds, float2 *val, float *aux, int c,
-                                           uint32_t pix0, int npix, float *aux2 = nullptr)
+                                           uint32_t pix0, int npix, int block, float *aux2 = nullptr)
 {
     constexpr bool kRanged = sizeof(T) != 4;
     constexpr int kEntry = lut_entry_bytes(INTERP);
     const int N = a.n_images, L = a.n_points;
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
     const int px = (int)threadIdx.x & (a.tp - 1);
-    const int n0 = (int)threadIdx.x >> a.tp_shift, nstep = (int)blockDim.x >> a.tp_shift;
+    const int n0 = (int)threadIdx.x >> a.tp_shift, nstep = block >> a.tp_shift;  // block = workgroup size (constant)
     const bool inb = px < npix;
     const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + (uint32_t)px;
     const uint32_t qg = ql + (uint32_t)c * a.tile.chan_skip + a.tile.base;  // TileMap::locate with the channel known
@@ -127,6 +130,123 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
     }
 }
 
+// ---- vectorised, prefetching variant of phase 1 -----------------------------------------------------------
+// Used when every image plane is 4-element aligned (host: PairArgs::vec).  A thread owns FOUR consecutive pixels of one
+// sample per pass and fetches them with one 4/8/16-byte load; the loads of the NEXT tile are issued before the pair
+// phase of the current one (issue) and consumed after it (commit), so HBM latency hides behind the pair arithmetic.
+// Tile columns are permuted so the LDS stores stay conflict-free: pixel 4*g + e lives in column e*(tp/4) + g.
+// Consumers treat columns as opaque; pixel_of_column() recovers the pixel where it matters (LUT row, bounds).
+template <typename T> struct RawVec;
+template <> struct RawVec<uint8_t> { using type = uint32_t; };
+template <> struct RawVec<uint16_t> { using type = uint2; };
+template <> struct RawVec<float> { using type = float4; };
+
+__device__ __forceinline__ uint8_t raw_elem(uint32_t v, int e) { return (uint8_t)(v >> (8 * e)); }
+__device__ __forceinline__ uint16_t raw_elem(uint2 v, int e) { return (uint16_t)((e < 2 ? v.x : v.y) >> (16 * (e & 1))); }
+__device__ __forceinline__ float raw_elem(float4 v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+__device__ __forceinline__ int pixel_of_column(const PairArgs &a, int col)
+{
+    if (!a.vec) return col;
+    const int gshift = a.tp_shift - 2;
+    return ((col & ((1 << gshift) - 1)) << 2) + (col >> gshift);
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would stall on the
+// prefetched HBM loads that are meant to stay in flight across the pair phase.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <typename T, int INTERP, int STD, bool WANT_COORD, int KB>
+struct VecStager {
+    using Vec = typename RawVec<T>::type;
+    Vec raw[KB];
+    float4 sraw[KB];
+
+    __device__ __forceinline__ void issue(const PairArgs &a, int c, uint32_t pix0, int npix, int block)
+    {
+        const int gshift = a.tp_shift - 2;
+        const int pg = (int)threadIdx.x & ((1 << gshift) - 1);
+        const int n0 = (int)threadIdx.x >> gshift, nstep = block >> gshift;
+        const bool inb = 4 * pg < npix;
+        const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + 4u * (uint32_t)pg;
+        const T *src = static_cast<const T *>(a.stack) + ql;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int n = n0 + k * nstep;
+            if (inb && n < a.n_images) {
+                raw[k] = *reinterpret_cast<const Vec *>(src + (int64_t)n * a.image_stride);
+                if constexpr (STD == CT_STD_EXPLICIT)
+                    sraw[k] = *reinterpret_cast<const float4 *>(a.std_stack + (int64_t)n * a.image_stride + ql);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void commit(const PairArgs &a, const char *lut_lds, float2 *val, float *aux, float *aux2,
+                                           int c, uint32_t pix0, int npix, int block)
+    {
+        constexpr bool kRanged = sizeof(T) != 4;
+        constexpr int kEntry = lut_entry_bytes(INTERP);
+        const int N = a.n_images, L = a.n_points;
+        const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
+        const int gshift = a.tp_shift - 2, G = 1 << gshift;
+        const int pg = (int)threadIdx.x & (G - 1);
+        const int n0 = (int)threadIdx.x >> gshift, nstep = block >> gshift;
+        const bool inb = 4 * pg < npix;
+        const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + 4u * (uint32_t)pg;
+        const uint32_t qg = ql + (uint32_t)c * a.tile.chan_skip + a.tile.base;
+        int row_off[4];
+        {
+            int r = lut_row<INTERP>(qg, c, a.channels);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                row_off[e] = r * L * kEntry;
+                if constexpr (INTERP != CT_INTERP_LOOKUP) r = r + 1 == a.channels ? 0 : r + 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int n = n0 + k * nstep;
+            if (n >= N) break;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float2 v = make_float2(0.0f, -INFINITY);
+                float ax = 0.0f, ax2 = 0.0f;
+                if (inb) {
+                    const float x = to_pixel<T>(raw_elem(raw[k], e), a.norm);
+                    float dfdx;
+                    const float lin = icrf_sample<INTERP, true, kRanged>(x, lut_lds + row_off[e], top, dfdx);
+                    const float d = x - 0.5f;
+                    const float gw = __builtin_amdgcn_exp2f((d * d) * a.neg_scale_log2e);
+                    const bool valid = x >= a.lower && x <= a.upper;
+                    v = make_float2(lin, valid ? gw : -INFINITY);
+                    float lsd = 0.0f;
+                    if constexpr (STD != CT_STD_NONE) {
+                        float sigma = a.std_value;
+                        if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;
+                        if constexpr (STD == CT_STD_EXPLICIT) sigma = raw_elem(sraw[k], e);
+                        lsd = fabsf(dfdx * sigma);  // icrf_training.py:117-126: |grads * stds|
+                    }
+                    if constexpr (WANT_COORD) {
+                        ax = fminf(fmaxf(x * top, 0.0f), top);
+                        ax2 = lsd;
+                    } else {
+                        ax = lsd;
+                    }
+                }
+                const int at = n * a.row_pitch + e * G + pg;
+                val[at] = v;
+                if constexpr (WANT_COORD || STD != CT_STD_NONE) aux[at] = ax;
+                if constexpr (WANT_COORD && STD != CT_STD_NONE) aux2[at] = ax2;
+            }
+        }
+    }
+};
+
 // sign(d) in {-1, 0, +1} without compares: d * 2^127 is >= 2 in magnitude for every normal d, the median clamps it.
 __device__ __forceinline__ float sign_of(float d)
 {
@@ -177,23 +297,42 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
     }
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
-    for (uint32_t t = blockIdx.x / C; t < tiles; t += gstep) {
+    VecStager<T, INTERP, STD, false, 8> stager;
+    const uint32_t t_first = blockIdx.x / C;
+    if (a.vec && t_first < tiles)
+        stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBlock);
+    for (uint32_t t = t_first; t < tiles; t += gstep) {
         const uint32_t pix0 = t * a.tp;
         const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
-        __syncthreads();  // previous tile's readers are done (also orders stage_lut before first use)
-        stage_tile<T, INTERP, STD, false>(a, lds, val, aux, c, pix0, npix);
-        __syncthreads();
+        lds_barrier();  // previous tile's readers are done (also orders stage_lut before first use)
+        if (a.vec) {
+            stager.commit(a, lds, val, aux, nullptr, c, pix0, npix, kBlock);
+            const uint32_t tn = t + gstep;  // next tile's loads fly during this tile's pair phase
+            if (tn < tiles) stager.issue(a, c, tn * a.tp, (int)min((uint32_t)a.tp, a.plane_local - tn * a.tp), kBlock);
+        } else {
+            stage_tile<T, INTERP, STD, false>(a, lds, val, aux, c, pix0, npix, kBlock);
+        }
+        lds_barrier();
+        const int ncol = a.vec ? a.tp : npix;
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             if (!live[s]) continue;
+#ifdef CT_DBG_FWD_SKIP_PAIRS
+            continue;
+#endif
             float f[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) f[k] = 0.0f;
             const float2 *vi = val + bi[s], *vj = val + bj[s];
             const float *xi = aux + bi[s], *xj = aux + bj[s];
+            // partial tiles: padding columns carry weight -inf and contribute nothing (their order is permuted when a.vec)
 #pragma unroll 8
-            for (int px = 0; px < npix; ++px) {
+            for (int px = 0; px < ncol; ++px) {
+#ifdef CT_DBG_FWD_NO_LDS
+                const float2 A = make_float2(rhi[s] + px, rlo[s]), Bv = make_float2(rlo[s] * px, rhi[s]);
+#else
                 const float2 A = vi[px], Bv = vj[px];
+#endif
                 // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
                 const float d1 = __builtin_fmaf(-Bv.x, rhi[s], A.x);
                 float diff = __builtin_fmaf(-Bv.x, rlo[s], d1);
@@ -367,15 +506,26 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
         }
     }
     // the wavefront index is uniform: readfirstlane lets the sample / partner loops run on the scalar unit
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int nwaves = kBwdBlock >> 6;
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
-    for (uint32_t t = blockIdx.x / C; t < tiles; t += gstep) {
+    VecStager<T, INTERP, STD, true, 4> stager;
+    const uint32_t t_first = blockIdx.x / C;
+    if (a.vec && t_first < tiles)
+        stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBwdBlock);
+    for (uint32_t t = t_first; t < tiles; t += gstep) {
         const uint32_t pix0 = t * a.tp;
         const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
-        __syncthreads();
-        stage_tile<T, INTERP, STD, true>(a, lds, val, aux, c, pix0, npix, lsdv);
-        __syncthreads();
+        lds_barrier();
+        if (a.vec) {
+            stager.commit(a, lds, val, aux, lsdv, c, pix0, npix, kBwdBlock);
+            const uint32_t tn = t + gstep;
+            if (tn < tiles) stager.issue(a, c, tn * a.tp, (int)min((uint32_t)a.tp, a.plane_local - tn * a.tp), kBwdBlock);
+        } else {
+            stage_tile<T, INTERP, STD, true>(a, lds, val, aux, c, pix0, npix, kBwdBlock, lsdv);
+        }
+        lds_barrier();
         const int col = min(lane, a.tp - 1);  // 32-pixel tiles (very large N): the upper half-wave idles in bounds
         const char *valb = reinterpret_cast<const char *>(val + col);
         const char *lsdb = reinterpret_cast<const char *>(lsdv + col);
@@ -421,11 +571,11 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
 #endif
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
-                const int px = lane + 64 * k;
-                if (px < npix && G[k] != 0.0f) {
+                const int colk = lane + 64 * k, px = pixel_of_column(a, colk);
+                if (colk < a.tp && px < npix && G[k] != 0.0f) {
                     const uint32_t qg = (uint32_t)c * (a.plane_local + a.tile.chan_skip) + a.tile.base + pix0 + (uint32_t)px;
                     double *hrow = hist64 + lut_row<INTERP>(qg, c, C) * L;
-                    const float s = aux[n * a.row_pitch + px];
+                    const float s = aux[n * a.row_pitch + colk];
                     const float Gk = G[k];
                     if constexpr (INTERP == CT_INTERP_LOOKUP) {
                         atomicAdd(&hrow[(int)rintf(s)], (double)Gk);
@@ -458,6 +608,228 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
         if (hist64[k] != 0.0) atomicAdd(&a.lut_grad[k], hist64[k]);
 }
 
+// ---- backward, every pair evaluated once (no uncertainty weighting) -------------------------------------------
+// Same mapping (wavefront <-> sample i, lane <-> tile column), but only the "own sample is i" entries are walked: the
+// shared part of the evaluation (residual, 1/es, mask, sign) serves both sides of the pair.  The i-side term stays in
+// a register; the j-side term goes to a per-tile (sample, column) float64 accumulator in LDS with ds_add_f64 on
+// lane-linear addresses (~9 cycles per wave-instruction, tools/lds_atomic_rates.hip -- the float32 LDS atomic costs
+// ~190, which is why an earlier float32 attempt at this design lost).  After a barrier every (sample, column) entry
+// is scattered into the (C, L) histogram.  ~14 VALU instructions per pair-pixel against 11 + 14 when each side is
+// evaluated separately.
+// Entry of the pair-once backward's global partner table: 32 bytes, read with one s_load_dwordx8 (uniform index,
+// constant address space) so every field arrives in an SGPR.
+struct OnceEntry {
+    int row;         // byte offset of the partner's row in val[] and gacc[]
+    float rhi, rlo;  // exposure ratio split in two floats
+    float cf;        // upstream coefficient of the pair for this channel (i-side factor)
+    float cfr;       // -cf * r (j-side factor)
+    int pad[3];
+};
+typedef int32_t Words8 __attribute__((ext_vector_type(8)));
+typedef const Words8 __attribute__((address_space(4))) *ConstWords;
+__device__ __forceinline__ OnceEntry load_entry(ConstWords table, int k)
+{
+    const Words8 w = table[k];
+    OnceEntry pe;
+    pe.row = w.s0;
+    pe.rhi = __int_as_float(w.s1);
+    pe.rlo = __int_as_float(w.s2);
+    pe.cf = __int_as_float(w.s3);
+    pe.cfr = __int_as_float(w.s4);
+    return pe;
+}
+
+// One pair, both sides.  Gi accumulates the own (i) side; gj is the partner's (j) side term.
+//   u_i = sign(q) w m dq/dI_i with q the (relative) residual = sign(diff) w m / |es|; sign(diff) * t is formed as
+//   clamp(diff * 2^127, -t, t): exact whenever |diff| * 2^127 >= t, and 0 at diff == 0.
+//   u_j = u_i (I_i + eps) / es; times -r cf it is the j-side term.
+template <bool REL>
+__device__ __forceinline__ void once_term(const OnceEntry &pe, float2 own, float2 oth, float &Gi, float &gj)
+{
+    const float Ii = own.x, Ij = oth.x;
+    const float d1 = __builtin_fmaf(-Ij, pe.rhi, Ii);
+    const float diff = __builtin_fmaf(-Ij, pe.rlo, d1);
+    const float wm = fmaxf(own.y + oth.y, 0.0f);  // -inf encoded mask
+    float ti = wm, qj = 1.0f;
+    if constexpr (REL) {
+        const float inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Ij, pe.rhi, 1e-6f));
+        ti = wm * fabsf(inv_es);
+        qj = (Ii + 1e-6f) * inv_es;
+    }
+    const float ui = __builtin_amdgcn_fmed3f(diff * 0x1p127f, -ti, ti);
+    const float uj = REL ? ui * qj : ui;
+    Gi = __builtin_fmaf(pe.cf, ui, Gi);
+    gj = pe.cfr * uj;
+}
+
+// Fills the workspace of the pair-once backward: first[N + 1] and, per channel, the i-side partner entries grouped by
+// sample (one workgroup per channel).  The entries are wavefront-uniform in the main kernel, which therefore reads
+// them with scalar loads (SGPR operands, no LDS traffic, no VALU moves).
+__global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int32_t *first, OnceEntry *table)
+{
+    __shared__ int sfirst[1025];
+    const int N = a.n_images, C = a.channels, c = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int n = 0; n < N; ++n) {
+            sfirst[n] = run;
+            for (int e = a.part_off[n]; e < a.part_off[n + 1]; ++e) run += a.part_pair[e] >= 0 ? 1 : 0;
+        }
+        sfirst[N] = run;
+    }
+    __syncthreads();
+    if (c == 0)
+        for (int n = threadIdx.x; n <= N; n += blockDim.x) first[n] = sfirst[n];
+    OnceEntry *tab = table + (size_t)c * a.n_pairs;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        int at = sfirst[n];
+        for (int e = a.part_off[n]; e < a.part_off[n + 1]; ++e) {
+            const int p = a.part_pair[e];
+            if (p < 0) continue;
+            const double r = a.ratio[p];
+            OnceEntry pe{};
+            pe.row = a.part_sample[e] * a.row_pitch * 8;
+            pe.rhi = (float)r;
+            pe.rlo = (float)(r - (double)pe.rhi);
+            pe.cf = (float)a.coef[(int64_t)p * C + c];
+            pe.cfr = -pe.cf * pe.rhi;
+            tab[at++] = pe;
+        }
+    }
+}
+
+template <typename T, int INTERP, bool REL>
+__global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs a)
+{
+    extern __shared__ __align__(16) char lds[];
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    const int C = a.channels, L = a.n_points, N = a.n_images;
+    const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
+    double *hist64 = reinterpret_cast<double *>(lds + lut_bytes);
+    double *gacc = reinterpret_cast<double *>(lds + a.val_offset);         // (N, row_pitch) dL/dI accumulators
+    float2 *val = reinterpret_cast<float2 *>(gacc + (size_t)N * a.row_pitch);
+    float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
+    int *colrow = reinterpret_cast<int *>(aux + (size_t)N * a.row_pitch);  // histogram row offset (row * L) per column
+    const int c = blockIdx.x % C;
+    // constant address space + uniform index = scalar loads (s_load_dwordx4 into SGPRs); the tables were written by
+    // the preceding launch and are read-only here
+    typedef const int32_t __attribute__((address_space(4))) *ConstInts;
+    ConstInts first = (ConstInts)(uintptr_t)a.first_g;
+    ConstWords ent = (ConstWords)(uintptr_t)(static_cast<const OnceEntry *>(a.table_g) + (size_t)c * a.n_pairs);
+    stage_lut<INTERP>(lds, a.lut, C, L);
+    for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int nwaves = kBwdBlock >> 6;
+    const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
+    const uint32_t gstep = gridDim.x / C;
+    VecStager<T, INTERP, CT_STD_NONE, true, 4> stager;
+    const uint32_t t_first = blockIdx.x / C;
+    if (a.vec && t_first < tiles)
+        stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBwdBlock);
+    const int col = min(lane, a.tp - 1);
+    for (uint32_t t = t_first; t < tiles; t += gstep) {
+        const uint32_t pix0 = t * a.tp;
+        const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
+        lds_barrier();  // the previous tile's scatter is done
+        if (a.vec) {
+            stager.commit(a, lds, val, aux, nullptr, c, pix0, npix, kBwdBlock);
+            const uint32_t tn = t + gstep;
+            if (tn < tiles) stager.issue(a, c, tn * a.tp, (int)min((uint32_t)a.tp, a.plane_local - tn * a.tp), kBwdBlock);
+        } else {
+            stage_tile<T, INTERP, CT_STD_NONE, true>(a, lds, val, aux, c, pix0, npix, kBwdBlock, nullptr);
+        }
+        for (int k = threadIdx.x; k < N * a.row_pitch; k += blockDim.x) gacc[k] = 0.0;
+        if ((int)threadIdx.x < a.tp) {  // the LUT row of a column depends on the pixel only (models/base.py:173-176)
+            const uint32_t px = (uint32_t)pixel_of_column(a, (int)threadIdx.x);
+            const uint32_t qg = (uint32_t)c * (a.plane_local + a.tile.chan_skip) + a.tile.base + pix0 + px;
+            colrow[threadIdx.x] = lut_row<INTERP>(qg, c, C) * L;
+        }
+        lds_barrier();
+#ifdef CT_DBG_ONCE_NO_PAIRS
+        if (a.tp < 0)
+#endif
+        {   // uniform control flow throughout: with 32-column tiles the upper half-wave works on a masked copy
+            const char *valb = reinterpret_cast<const char *>(val + col);
+            char *gaccb = reinterpret_cast<char *>(gacc + col);
+            for (int n = wave; n < N; n += nwaves) {
+                float2 own = val[n * a.row_pitch + col];
+                if (lane >= a.tp) own.y = -INFINITY;
+                float Gi = 0.0f;
+                const int e0 = first[n], e1 = first[n + 1];
+                // groups of kGroup partners: all LDS reads first, then the arithmetic, then the atomics -- the compiler
+                // cannot hoist reads over the ds_add_f64 of the previous partner, so the order is spelled out
+                constexpr int kGroup = 4;
+                int e = e0;
+                for (; e + kGroup <= e1; e += kGroup) {
+                    OnceEntry pe[kGroup];
+                    float2 oth[kGroup];
+                    float gj[kGroup];
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u) pe[u] = load_entry(ent, e + u);
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u) oth[u] = *reinterpret_cast<const float2 *>(valb + pe[u].row);
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u) once_term<REL>(pe[u], own, oth[u], Gi, gj[u]);
+#ifdef CT_DBG_ONCE_NO_ATOMIC
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u) Gi += gj[u];
+#else
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u)
+                        atomicAdd(reinterpret_cast<double *>(gaccb + pe[u].row), (double)gj[u]);
+#endif
+                }
+                for (; e < e1; ++e) {
+                    const OnceEntry pe = load_entry(ent, e);
+                    const float2 oth = *reinterpret_cast<const float2 *>(valb + pe.row);
+                    float gj;
+                    once_term<REL>(pe, own, oth, Gi, gj);
+                    atomicAdd(reinterpret_cast<double *>(gaccb + pe.row), (double)gj);
+                }
+                atomicAdd(&gacc[n * a.row_pitch + col], (double)Gi);
+            }
+        }
+        lds_barrier();
+#ifdef CT_DBG_ONCE_NO_SCATTER
+        if (a.tp > 0) continue;
+#endif
+        // columns beyond the plane's end carry weight -inf, so their accumulators are exactly zero: no bounds test
+        for (int k = threadIdx.x; k < N * a.tp; k += blockDim.x) {
+            const int n = k >> a.tp_shift, colk = k & (a.tp - 1);
+            const float Gk = (float)gacc[n * a.row_pitch + colk];
+            if (Gk != 0.0f) {
+                double *hrow = hist64 + colrow[colk];
+                const float s = aux[n * a.row_pitch + colk];
+                if constexpr (INTERP == CT_INTERP_LOOKUP) {
+                    atomicAdd(&hrow[(int)rintf(s)], (double)Gk);
+                } else {
+                    const float fl = floorf(s);
+                    const int i0 = (int)fl;
+                    const float tt = s - fl;
+                    if constexpr (INTERP == CT_INTERP_LINEAR) {
+                        const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
+                        atomicAdd(&hrow[i0], (double)(Gk * (1.0f - tt)));
+                        atomicAdd(&hrow[i1], (double)(Gk * tt));
+                    } else {
+                        const float t2 = tt * tt, t3 = t2 * tt;
+                        const float w0 = -0.5f * t3 + t2 - 0.5f * tt, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
+                        const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * tt, w3 = 0.5f * t3 - 0.5f * t2;
+                        const int im = i0 > 0 ? i0 - 1 : 0, i1 = i0 + 1 < L ? i0 + 1 : L - 1,
+                                  i2 = i0 + 2 < L ? i0 + 2 : L - 1;
+                        atomicAdd(&hrow[im], (double)(Gk * w0));
+                        atomicAdd(&hrow[i0], (double)(Gk * w1));
+                        atomicAdd(&hrow[i1], (double)(Gk * w2));
+                        atomicAdd(&hrow[i2], (double)(Gk * w3));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * L; k += blockDim.x)
+        if (hist64[k] != 0.0) atomicAdd(&a.lut_grad[k], hist64[k]);
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 static int pick_tile(int n_images, size_t fixed_bytes, int bytes_per_entry, int want)
 {
@@ -468,6 +840,18 @@ static int pick_tile(int n_images, size_t fixed_bytes, int bytes_per_entry, int 
         if (need <= budget) return tp;
     }
     return 0;
+}
+
+// The vectorised staging needs every plane of every image to start on a 4-element boundary (and the base pointers
+// aligned accordingly), and at most `max_passes` samples per thread.
+template <typename T>
+static int vec_ok(const PairArgs &a, int block, int max_passes)
+{
+    const int nstep = block / (a.tp / 4);
+    const bool aligned = a.plane_local % 4 == 0 && a.image_stride % 4 == 0 &&
+                         reinterpret_cast<uintptr_t>(a.stack) % (4 * sizeof(T)) == 0 &&
+                         (a.std_stack == nullptr || reinterpret_cast<uintptr_t>(a.std_stack) % 16 == 0);
+    return aligned && (a.n_images + nstep - 1) / nstep <= max_passes ? 1 : 0;
 }
 
 template <typename T, int INTERP, int STD, int PPT>
@@ -498,6 +882,7 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
     a.tp = tp;
     a.tp_shift = tp == 64 ? 6 : 5;
     a.row_pitch = tp + 1;
+    a.vec = vec_ok<T>(a, kBlock, 8);
     const size_t lds = lut_bytes + (size_t)a.n_images * a.row_pitch * entry;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
     int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
@@ -565,6 +950,7 @@ static int bwd_launch_pairs(PairArgs a, hipStream_t s)
     a.tp_shift = tp == 128 ? 7 : (tp == 64 ? 6 : 5);
     a.val_offset = (int32_t)fixed;
     a.row_pitch = tp + 1;
+    a.vec = vec_ok<T>(a, kBwdBlock, 4);
     const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
     int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
@@ -583,14 +969,59 @@ static int bwd_launch_pairs(PairArgs a, hipStream_t s)
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
+static size_t once_workspace_bytes(int n_images, int n_pairs, int channels)
+{
+    return (((size_t)(n_images + 1) * 4 + 31) & ~(size_t)31) + (size_t)channels * n_pairs * sizeof(OnceEntry);
+}
+
 template <typename T, int INTERP>
-static int bwd_dispatch_std(const PairArgs &a, int std_mode, hipStream_t s)
+static int bwd_launch_once(PairArgs a, void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    if (a.n_images > 1024) return CT_ERR_TOO_LARGE;
+    if (!workspace || workspace_bytes < once_workspace_bytes(a.n_images, a.n_pairs, a.channels) ||
+        reinterpret_cast<uintptr_t>(workspace) % 32 != 0)
+        return CT_ERR_INVALID_ARGUMENT;
+    const size_t lut_bytes = ((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15;
+    const size_t cl = (size_t)a.channels * a.n_points;
+    // LUT | float64 histogram | (N, pitch) float64 accumulators | staged tile
+    const size_t fixed = ((lut_bytes + cl * 8 + 15) & ~(size_t)15) + 256;  // + colrow[tp] at the very end
+    const int per_sample = 8 + 12;  // accumulator + (value, weight) + LUT coordinate, per tile column (+ 256 B of rows)
+    const int tp = pick_tile(a.n_images, fixed, per_sample, 64);
+    if (tp == 0) return CT_ERR_TOO_LARGE;
+    a.tp = tp;
+    a.tp_shift = tp == 64 ? 6 : 5;
+    a.val_offset = (int32_t)(fixed - 256);
+    a.row_pitch = tp + 1;
+    a.vec = vec_ok<T>(a, kBwdBlock, 4);
+    int32_t *first = static_cast<int32_t *>(workspace);
+    OnceEntry *table = reinterpret_cast<OnceEntry *>(static_cast<char *>(workspace) +
+                                                     (((size_t)(a.n_images + 1) * 4 + 31) & ~(size_t)31));
+    a.first_g = first;
+    a.table_g = table;
+    hipLaunchKernelGGL(pair_entries_kernel, dim3(a.channels), dim3(256), 0, s, a, first, table);
+    const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
+    const uint32_t tiles = (a.plane_local + tp - 1) / tp;
+    int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
+    const int grid = per_chan * a.channels;
+    if (a.use_relative)
+        hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, true>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+    else
+        hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, false>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int INTERP>
+static int bwd_dispatch_std(const PairArgs &a, int std_mode, void *ws, size_t ws_bytes, hipStream_t s)
 {
 #ifdef CT_PAIRS_MINIMAL
+#ifdef CT_DBG_BWD_TWO_SIDED
     return std_mode == CT_STD_NONE ? bwd_launch_pairs<T, INTERP, CT_STD_NONE>(a, s) : CT_ERR_UNSUPPORTED;
+#else
+    return std_mode == CT_STD_NONE ? bwd_launch_once<T, INTERP>(a, ws, ws_bytes, s) : CT_ERR_UNSUPPORTED;
+#endif
 #endif
     switch (std_mode) {
-        case CT_STD_NONE: return bwd_launch_pairs<T, INTERP, CT_STD_NONE>(a, s);
+        case CT_STD_NONE: return bwd_launch_once<T, INTERP>(a, ws, ws_bytes, s);
         case CT_STD_CONSTANT: return bwd_launch_pairs<T, INTERP, CT_STD_CONSTANT>(a, s);
         case CT_STD_MULTIPLIER: return bwd_launch_pairs<T, INTERP, CT_STD_MULTIPLIER>(a, s);
         case CT_STD_EXPLICIT: return bwd_launch_pairs<T, INTERP, CT_STD_EXPLICIT>(a, s);
@@ -599,15 +1030,15 @@ static int bwd_dispatch_std(const PairArgs &a, int std_mode, hipStream_t s)
 }
 
 template <typename T>
-static int bwd_dispatch(const PairArgs &a, int interp, int std_mode, hipStream_t s)
+static int bwd_dispatch(const PairArgs &a, int interp, int std_mode, void *ws, size_t ws_bytes, hipStream_t s)
 {
 #ifdef CT_PAIRS_MINIMAL
-    return interp == CT_INTERP_LINEAR ? bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, s) : CT_ERR_UNSUPPORTED;
+    return interp == CT_INTERP_LINEAR ? bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, ws, ws_bytes, s) : CT_ERR_UNSUPPORTED;
 #endif
     switch (interp) {
-        case CT_INTERP_LOOKUP: return bwd_dispatch_std<T, CT_INTERP_LOOKUP>(a, std_mode, s);
-        case CT_INTERP_LINEAR: return bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, s);
-        case CT_INTERP_CATMULL: return bwd_dispatch_std<T, CT_INTERP_CATMULL>(a, std_mode, s);
+        case CT_INTERP_LOOKUP: return bwd_dispatch_std<T, CT_INTERP_LOOKUP>(a, std_mode, ws, ws_bytes, s);
+        case CT_INTERP_LINEAR: return bwd_dispatch_std<T, CT_INTERP_LINEAR>(a, std_mode, ws, ws_bytes, s);
+        case CT_INTERP_CATMULL: return bwd_dispatch_std<T, CT_INTERP_CATMULL>(a, std_mode, ws, ws_bytes, s);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
@@ -693,7 +1124,7 @@ extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float 
                                     const double *ratio_dev, int32_t n_pairs, const int32_t *partner_offsets_dev,
                                     const int32_t *partner_sample_dev, const int32_t *partner_pair_dev,
                                     const ct_pair_params *params, const double *coef_dev, const double *smean_dev,
-                                    double *lut_grad_dev, void *stream)
+                                    double *lut_grad_dev, void *workspace_dev, int64_t workspace_bytes, void *stream)
 {
     using namespace ct;
     if (!params) return CT_ERR_INVALID_ARGUMENT;
@@ -704,7 +1135,8 @@ extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float 
     int rc = fill_common(a, stack_dev, n_images, geom, std_dev, icrf, &prm, n_pairs);
     if (rc != CT_OK) return rc;
     if (n_pairs == 0) return CT_OK;
-    if (!ratio_dev || !partner_offsets_dev || !partner_sample_dev || !partner_pair_dev || !coef_dev || !lut_grad_dev)
+    if (!ratio_dev || !partner_offsets_dev || !partner_sample_dev || !partner_pair_dev || !coef_dev || !lut_grad_dev ||
+        workspace_bytes < 0)
         return CT_ERR_INVALID_ARGUMENT;
     if (icrf->interp == CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
     if (prm.std_mode != CT_STD_NONE) {
@@ -723,12 +1155,18 @@ extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float 
 #ifndef CT_PAIRS_MINIMAL
         case CT_DTYPE_U8:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
-            return bwd_dispatch<uint8_t>(a, icrf->interp, prm.std_mode, s);
-        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, prm.std_mode, s);
+            return bwd_dispatch<uint8_t>(a, icrf->interp, prm.std_mode, workspace_dev, (size_t)workspace_bytes, s);
+        case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, prm.std_mode, workspace_dev, (size_t)workspace_bytes, s);
 #endif
         case CT_DTYPE_U16:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
-            return bwd_dispatch<uint16_t>(a, icrf->interp, prm.std_mode, s);
+            return bwd_dispatch<uint16_t>(a, icrf->interp, prm.std_mode, workspace_dev, (size_t)workspace_bytes, s);
     }
     return CT_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t ct_pair_residual_bwd_workspace(int32_t n_images, int32_t n_pairs, int32_t channels)
+{
+    if (n_images < 0 || n_pairs < 0 || channels < 0) return 0;
+    return (int64_t)ct::once_workspace_bytes(n_images, n_pairs, channels);
 }

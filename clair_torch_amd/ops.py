@@ -254,6 +254,16 @@ class PairList:
         self.part_off = torch.tensor(offsets, dtype=torch.int32, device=device)
         self.part_sample = torch.tensor(samples or [0], dtype=torch.int32, device=device)
         self.part_pair = torch.tensor(codes or [0], dtype=torch.int32, device=device)
+        self._workspace = {}
+
+    def workspace(self, channels: int) -> torch.Tensor:
+        """Scratch for ct_pair_residual_bwd (its per-channel partner tables), allocated once per channel count."""
+        ws = self._workspace.get(channels)
+        if ws is None:
+            nbytes = int(nv.load().ct_pair_residual_bwd_workspace(self.n_images, self.n_pairs, channels))
+            ws = torch.empty(max(nbytes, 32), dtype=torch.uint8, device=self.i.device)
+            self._workspace[channels] = ws
+        return ws
 
 
 def pair_residual_sums(stack: torch.Tensor, pairs: PairList, *, lut: Optional[torch.Tensor], interp: Optional[str],
@@ -327,12 +337,13 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
         raise ValueError(f"coef must be (P={pairs.n_pairs}, C={c}), got {tuple(coef.shape)}")
     grad = torch.zeros((c, lut.shape[1]), dtype=torch.float64, device=dev)
     if pairs.n_pairs:
+        ws = pairs.workspace(c)
         with torch.cuda.device(dev):
             rc = nv.load().ct_pair_residual_bwd(_ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), n,
                                                 ctypes.byref(geom), _ptr(std), ctypes.byref(icrf), _ptr(pairs.ratio),
                                                 pairs.n_pairs, _ptr(pairs.part_off), _ptr(pairs.part_sample),
                                                 _ptr(pairs.part_pair), ctypes.byref(prm), _ptr(coef), _ptr(smean),
-                                                _ptr(grad), _stream(dev))
+                                                _ptr(grad), _ptr(ws), ws.numel(), _stream(dev))
         nv.check(rc, "ct_pair_residual_bwd")
     del lut_keep
     return grad

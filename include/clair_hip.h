@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CT_ABI_VERSION 1
+#define CT_ABI_VERSION 2
 
 /* status codes */
 #define CT_OK 0
@@ -180,12 +180,17 @@ int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float max_code, i
  *   1/(err + 1e-6) then depend on the LUT (relative loss), and the backward needs smean_dev (P, C) float64 = the
  *   spatial means of the forward:  d mean = sum m [w dv + (v - mean) dw] / sum w m.  smean_dev may be NULL otherwise.
  *   lut_grad_dev (C, L) float64, ACCUMULATED (+=)
+ *   workspace_dev: caller-owned scratch of at least ct_pair_residual_bwd_workspace(n_images, n_pairs, channels) bytes,
+ *   32-byte aligned (the library allocates nothing): the per-channel partner tables the kernel reads with scalar loads
+ *   are built there by a small preparatory launch on the same stream.  Contents are undefined afterwards.
  */
+int64_t ct_pair_residual_bwd_workspace(int32_t n_images, int32_t n_pairs, int32_t channels);
 int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
                          const ct_geometry *geom, const float *std_dev, const ct_icrf *icrf, const double *ratio_dev,
                          int32_t n_pairs, const int32_t *partner_offsets_dev, const int32_t *partner_sample_dev,
                          const int32_t *partner_pair_dev, const ct_pair_params *params, const double *coef_dev,
-                         const double *smean_dev, double *lut_grad_dev, void *stream);
+                         const double *smean_dev, double *lut_grad_dev, void *workspace_dev, int64_t workspace_bytes,
+                         void *stream);
 
 /*
  * Flat-field correction epilogues (clair_torch/inference/hdr_merge.py:131-153, linearization.py:48-57,118-130;

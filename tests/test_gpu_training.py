@@ -131,40 +131,59 @@ def test_train_icrf_uncertainty_weighted_run(dev):
     assert np.max(np.abs(model.icrf.detach().cpu().numpy() - ref)) < 5e-6
 
 
-def test_lut_gradient_vs_eager_oracle_large(dev):
-    """A bigger, ragged case (plane not a multiple of the tile, 9 exposures, 64-sample LUT) against the eager
-    float64-residual oracle; also checks the tile decomposition: two row bands sum to the whole."""
+@pytest.mark.parametrize("h,w", [(61, 47), (60, 46), (64, 128)])
+@pytest.mark.parametrize("kind", ["float", "u16", "u8"])
+def test_lut_gradient_vs_eager_oracle_large(dev, h, w, kind):
+    """Bigger, ragged cases (9 exposures, 64-sample LUT) against the eager float64-residual oracle, over the staging
+    variants of the kernels: an odd plane (61x47: scalar staging), a 4-aligned plane that is not a multiple of the tile
+    (60x46: vectorised staging with a partial last tile), whole tiles (64x128); float pixels, uint16 and uint8 codes.
+    Also checks the tile decomposition: two row bands sum to the whole."""
     from clair_torch_amd import ops
     from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
     from clair_torch_amd.training import linearity_loss
+    from oracle import ct_oracle as oc
     from oracle import eager_torch as oe
     gen = torch.Generator().manual_seed(21)
-    n, c, h, w = 9, 3, 61, 47
+    n, c = 9, 3
     t = torch.tensor([0.001 * 2.0 ** (k / 2.0) for k in range(n)], dtype=torch.float64)
     e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / float(torch.sqrt(t[0] * t[-1])))
     x = ((e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0, 1) ** (1 / 2.2)).float()
     x = (x + 0.01 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    max_code = None
+    if kind != "float":
+        max_code = 65535 if kind == "u16" else 255
+        codes = torch.round(x * max_code).to(torch.int32).numpy().astype(np.uint16 if kind == "u16" else np.uint8)
+        x = torch.from_numpy(oc.normalize_codes(codes))   # what the reference sees after CastTo + Normalize
+        dev_x = torch.from_numpy(codes).to(dev)
+    else:
+        dev_x = x.to(dev)
     lut0 = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.9, 2.2, 2.5)])
     lo = lut0.clone().requires_grad_(True)
     _, lin_o, sp_o = oe.training_loss(x, None, t, lo, "linear", 0.25, 1 / 255, 254 / 255, True, False)
     grad_o = torch.autograd.grad(lin_o.sum(), lo)[0]
     i, j, r = get_valid_exposure_pairs(t, 0.25)
-    dev_x = x.to(dev)
     pairs = ops.PairList(i, j, r, n, dev)
     lut = lut0.to(dev).requires_grad_(True)
     lin, sp = linearity_loss(lut, dev_x, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
-                             use_unc_weight=False)
+                             use_unc_weight=False, max_code=max_code)
     grad = torch.autograd.grad(lin.sum(), lut)[0]
     assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="spatial")
     assert_parity(lin.detach().cpu().numpy(), lin_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="lin loss")
     assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="lut grad")
-    # tiles: sums are additive over row bands when the global geometry is passed
-    kw = dict(lut=lut.detach(), interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False)
+    # tiles: sums and LUT gradients are additive over row bands when the global geometry is passed
+    kw = dict(lut=lut.detach(), interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False,
+              max_code=max_code)
     whole = ops.pair_residual_sums(dev_x, pairs, level=1, **kw)
+    bands = ((0, 20), (20, h))
     parts = [ops.pair_residual_sums(dev_x[:, :, r0:r1].contiguous(), pairs, level=1,
-                                    tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw)
-             for r0, r1 in ((0, 20), (20, 61))]
+                                    tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw) for r0, r1 in bands]
     assert_parity((parts[0] + parts[1]).cpu().numpy(), whole.cpu().numpy(), rtol=1e-6, norm_tol=1e-6, what="tiles")
+    coef = torch.rand((pairs.n_pairs, c), generator=gen, dtype=torch.float64).to(dev) * 1e-4
+    g_whole = ops.pair_residual_lut_grad(dev_x, pairs, coef, **kw)
+    g_parts = [ops.pair_residual_lut_grad(dev_x[:, :, r0:r1].contiguous(), pairs, coef,
+                                          tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw) for r0, r1 in bands]
+    assert_parity((g_parts[0] + g_parts[1]).cpu().numpy(), g_whole.cpu().numpy(), rtol=1e-6, norm_tol=1e-6,
+                  what="gradient tiles")
 
 
 @pytest.mark.parametrize("sname", ["none", "multiplier"])

@@ -98,6 +98,9 @@ int main(int argc, char **argv)
     CHECK(hipMemcpy(d_pp, pp.data(), pp.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_coef, coef.data(), coef.size() * 8, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice));
+    const int64_t ws_bytes = ct_pair_residual_bwd_workspace(N, P, C);
+    void *d_ws;
+    CHECK(hipMalloc(&d_ws, ws_bytes));
     ct_geometry g{};
     g.channels = C;
     g.h_tile = g.h_global = S;
@@ -127,7 +130,7 @@ int main(int argc, char **argv)
         if (rep) ms_f += t;
         CHECK(hipEventRecord(e0));
         rc = ct_pair_residual_bwd(stack, CT_DTYPE_U16, 65535.0f, N, &g, nullptr, &icrf, d_r, P, d_off, d_ps, d_pp, &prm,
-                                  d_coef, nullptr, d_grad, nullptr);
+                                  d_coef, nullptr, d_grad, d_ws, ws_bytes, nullptr);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&t, e0, e1));
