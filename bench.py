@@ -212,7 +212,16 @@ def run_train(args, rank, world, dev):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: {n_exp}-exposure {h}x{w}x3 uint16 stack, {pairs.n_pairs} pairs, relative loss"},
-            "roofline": {"bound": "valu", "achieved": None, "peak": 157.3, "unit": "TFLOP/s", "frac": None, "traffic": None}}
+            "roofline": _train_roofline(pairs.n_pairs, 3 * h * w, elapsed / args.steps)}
+
+
+def _train_roofline(n_pairs, elements, seconds):
+    """SURVEY 8(d) convention for C3: ~12 flop per pair and pixel-channel forward and the same again backward, against
+    the 157.3 TFLOP/s float32 vector peak.  Whole optimizer step (both kernels + Adam), host clock."""
+    flops = 2.0 * 12.0 * n_pairs * elements
+    achieved = flops / seconds / 1e12
+    return {"bound": "valu", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": round(achieved / 157.3, 4), "traffic": None}
 
 
 def measured_traffic(key):

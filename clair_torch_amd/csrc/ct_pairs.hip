@@ -317,9 +317,6 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             if (!live[s]) continue;
-#ifdef CT_DBG_FWD_SKIP_PAIRS
-            continue;
-#endif
             float f[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) f[k] = 0.0f;
@@ -328,11 +325,7 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
             // partial tiles: padding columns carry weight -inf and contribute nothing (their order is permuted when a.vec)
 #pragma unroll 8
             for (int px = 0; px < ncol; ++px) {
-#ifdef CT_DBG_FWD_NO_LDS
-                const float2 A = make_float2(rhi[s] + px, rlo[s]), Bv = make_float2(rlo[s] * px, rhi[s]);
-#else
                 const float2 A = vi[px], Bv = vj[px];
-#endif
                 // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
                 const float d1 = __builtin_fmaf(-Bv.x, rhi[s], A.x);
                 float diff = __builtin_fmaf(-Bv.x, rlo[s], d1);
@@ -394,12 +387,14 @@ struct PartnerEntry {  // 16 bytes: one broadcast ds_read_b128 per partner
     float cf;   // upstream coefficient; without uncertainty weighting the side's constant factor is folded in
 };
 
-// Design note (measured, C3 shape): evaluating every pair ONCE (own-side gradient in a register, partner-side via
-// ds_add_f32 into a per-tile (sample, pixel) buffer) was tried and is 2-3.5x SLOWER (64-99 ms vs 28.6 ms): one LDS
-// float atomic per pair-pixel serialises the LDS pipe.  Evaluating each pair from both of its samples costs ~1.6x the
-// VALU work but keeps the inner loop free of LDS writes.
-// 512 threads (8 waves) per workgroup: at N = 64 the staged tile + partner entries take ~90 KB of LDS, so only one
-// workgroup fits a CU; eight waves keep two per SIMD to cover the LDS latency of the partner loop.
+// Two backward kernels share this section.  pair_bwd_kernel evaluates each pair from both of its samples (own-side
+// gradient in a register, no LDS writes in the inner loop); it serves the uncertainty-weighted loss, whose extra
+// d(weight)/dI terms differ per side.  pair_bwd_once_kernel (further down) evaluates each pair once and is used
+// otherwise.  History: the first pair-once attempt accumulated the partner side with ds_add_f32 and was 2-3.5x slower
+// -- the float32 LDS atomic costs ~190 cycles per wave-instruction on gfx950 for any address pattern, where
+// ds_add_f64 costs ~9 (lane-linear) to ~20 (random); see tools/lds_atomic_rates.hip.
+// 1024 threads (16 waves) per workgroup: at N = 64 the staged tile takes 90-130 KB of LDS, so one workgroup fits a
+// CU and it has to bring all the wavefronts the SIMDs get.
 constexpr int kBwdBlock = 1024;
 
 // dL/dI_own contribution of one partner entry (lane = pixel).  OWN_IS_I: the own sample is the pair's first image.
@@ -538,11 +533,7 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
                 own_sd[k] = kUnc ? lsdv[n * a.row_pitch + col + 64 * k] : 0.0f;
                 G[k] = 0.0f;
             }
-#ifdef CT_DBG_SKIP_PAIRS
-            const int e0 = 0, em = 0, e1 = 0;
-#else
             const int e0 = a.part_off[n], em = __builtin_amdgcn_readfirstlane(split[n]), e1 = a.part_off[n + 1];
-#endif
 #pragma unroll 4
             for (int e = e0; e < em; ++e) {
                 const PartnerEntry pe = ent[e];
@@ -565,10 +556,6 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
                     partner_term<REL, kUnc, false>(G[k], pe, sm, own[k], own_sd[k], oth, oth_sd);
                 }
             }
-#ifdef CT_DBG_SKIP_SCATTER
-            if (G[0] == 123.0f) hist64[0] = G[PPL - 1];
-            continue;
-#endif
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
                 const int colk = lane + 64 * k, px = pixel_of_column(a, colk);
@@ -669,13 +656,19 @@ __global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int
 {
     __shared__ int sfirst[1025];
     const int N = a.n_images, C = a.channels, c = blockIdx.x;
-    if (threadIdx.x == 0) {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {  // i-side entry count of sample n ...
+        int cnt = 0;
+        for (int e = a.part_off[n]; e < a.part_off[n + 1]; ++e) cnt += a.part_pair[e] >= 0 ? 1 : 0;
+        sfirst[n + 1] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // ... turned into offsets (N <= 1024: a serial scan over LDS is a few microseconds)
         int run = 0;
-        for (int n = 0; n < N; ++n) {
+        sfirst[0] = 0;
+        for (int n = 1; n <= N; ++n) {
+            run += sfirst[n];
             sfirst[n] = run;
-            for (int e = a.part_off[n]; e < a.part_off[n + 1]; ++e) run += a.part_pair[e] >= 0 ? 1 : 0;
         }
-        sfirst[N] = run;
     }
     __syncthreads();
     if (c == 0)
@@ -745,9 +738,6 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
             colrow[threadIdx.x] = lut_row<INTERP>(qg, c, C) * L;
         }
         lds_barrier();
-#ifdef CT_DBG_ONCE_NO_PAIRS
-        if (a.tp < 0)
-#endif
         {   // uniform control flow throughout: with 32-column tiles the upper half-wave works on a masked copy
             const char *valb = reinterpret_cast<const char *>(val + col);
             char *gaccb = reinterpret_cast<char *>(gacc + col);
@@ -770,14 +760,9 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
                     for (int u = 0; u < kGroup; ++u) oth[u] = *reinterpret_cast<const float2 *>(valb + pe[u].row);
 #pragma unroll
                     for (int u = 0; u < kGroup; ++u) once_term<REL>(pe[u], own, oth[u], Gi, gj[u]);
-#ifdef CT_DBG_ONCE_NO_ATOMIC
-#pragma unroll
-                    for (int u = 0; u < kGroup; ++u) Gi += gj[u];
-#else
 #pragma unroll
                     for (int u = 0; u < kGroup; ++u)
                         atomicAdd(reinterpret_cast<double *>(gaccb + pe[u].row), (double)gj[u]);
-#endif
                 }
                 for (; e < e1; ++e) {
                     const OnceEntry pe = load_entry(ent, e);
@@ -790,9 +775,6 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
             }
         }
         lds_barrier();
-#ifdef CT_DBG_ONCE_NO_SCATTER
-        if (a.tp > 0) continue;
-#endif
         // columns beyond the plane's end carry weight -inf, so their accumulators are exactly zero: no bounds test
         for (int k = threadIdx.x; k < N * a.tp; k += blockDim.x) {
             const int n = k >> a.tp_shift, colk = k & (a.tp - 1);
@@ -1014,11 +996,7 @@ template <typename T, int INTERP>
 static int bwd_dispatch_std(const PairArgs &a, int std_mode, void *ws, size_t ws_bytes, hipStream_t s)
 {
 #ifdef CT_PAIRS_MINIMAL
-#ifdef CT_DBG_BWD_TWO_SIDED
-    return std_mode == CT_STD_NONE ? bwd_launch_pairs<T, INTERP, CT_STD_NONE>(a, s) : CT_ERR_UNSUPPORTED;
-#else
     return std_mode == CT_STD_NONE ? bwd_launch_once<T, INTERP>(a, ws, ws_bytes, s) : CT_ERR_UNSUPPORTED;
-#endif
 #endif
     switch (std_mode) {
         case CT_STD_NONE: return bwd_launch_once<T, INTERP>(a, ws, ws_bytes, s);
