@@ -186,6 +186,43 @@ def test_lut_gradient_vs_eager_oracle_large(dev, h, w, kind):
                   what="gradient tiles")
 
 
+@pytest.mark.parametrize("mode", ["linear", "lookup_fwd", "catmull"])
+def test_many_exposures_narrow_tiles(dev, mode):
+    """128 exposures: the kernels fall back to 32-column tiles (LDS budget) and walk the pair list in several launches;
+    every pair passes the threshold-free list (8128 pairs).  Sums and LUT gradient against the eager oracle."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.training import linearity_loss
+    from oracle import eager_torch as oe
+    gen = torch.Generator().manual_seed(5)
+    n, c, h, w = 128, 3, 12, 20
+    t = torch.tensor([0.001 * 2.0 ** (k / 16.0) for k in range(n)], dtype=torch.float64)
+    e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / float(torch.sqrt(t[0] * t[-1])))
+    x = ((e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0, 1) ** (1 / 2.2)).float()
+    x = (x + 0.01 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    lut0 = torch.stack([torch.linspace(0, 1, 32) ** p for p in (1.9, 2.2, 2.5)])
+    i, j, r = get_valid_exposure_pairs(t, None)
+    assert i.numel() == n * (n - 1) // 2
+    pairs = ops.PairList(i, j, r, n, dev)
+    dev_x = x.to(dev)
+    if mode == "lookup_fwd":   # LOOKUP has no LUT gradient in the reference either: forward statistics only
+        _, sp_o, _, _ = oe.linearity_statistics(x, None, t, lut0, "lookup", None, 1 / 255, 254 / 255, True, False)
+        sums = ops.pair_residual_sums(dev_x, pairs, lut=lut0.to(dev), interp="lookup", lower=1 / 255, upper=254 / 255,
+                                      use_relative=True, use_unc_weight=False)
+        sp = sums[..., 1] / sums[..., 0].clamp(min=1e-8)
+        assert_parity(sp.cpu().numpy(), sp_o.numpy(), rtol=1e-5, norm_tol=2e-6, what="spatial (lookup)")
+        return
+    lo = lut0.clone().requires_grad_(True)
+    _, lin_o, sp_o = oe.training_loss(x, None, t, lo, mode, None, 1 / 255, 254 / 255, True, False)
+    grad_o = torch.autograd.grad(lin_o.sum(), lo)[0]
+    lut = lut0.to(dev).requires_grad_(True)
+    lin, sp = linearity_loss(lut, dev_x, pairs, interp=mode, lower=1 / 255, upper=254 / 255, use_relative=True,
+                             use_unc_weight=False)
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="spatial")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="lut grad")
+
+
 @pytest.mark.parametrize("sname", ["none", "multiplier"])
 @pytest.mark.parametrize("mname", ["nomodel", "linear"])
 def test_measure_linearity_api(dev, sname, mname):
