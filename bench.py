@@ -13,7 +13,7 @@ all_gather of per-band statistics runs once after the timed region (the C5 "gath
 
 The JSON carries `roofline` (HBM: algorithmic bytes / mean kernel time from device events on the launch stream, against
 the 8 TB/s spec peak) and `cpu_baseline` (the reference-equivalent eager-PyTorch path of oracle/eager_torch.py timed on
-the host cores over a bounded sample; N = 1, rank 0 only).  Other workloads (--workload linearize|train) are for
+the host cores over a bounded sample; N = 1, rank 0 only).  Other workloads (--workload linearize|train|flatfield|video) are for
 development and print the same shape of line.
 """
 import argparse
@@ -174,6 +174,78 @@ def run_linearize(args, rank, world, dev):
                          "traffic": None}}
 
 
+def _timed_kernel(step, args):
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, e0.elapsed_time(e1) / args.steps
+
+
+def _hbm_roofline(bytes_alg, kernel_ms):
+    gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+
+
+def run_flatfield(args, rank, world, dev):
+    """flat-field epilogue of compute_hdr_image on a merged 4096x4096x3 image (float64 mean, float32
+    variance, float32 flat field + its std): one ct_flatfield_sums + one ct_flatfield_apply per step."""
+    from clair_torch_amd import ops
+    c, h, w = 3, 4096, 4096
+    gen = torch.Generator(device=dev).manual_seed(3)
+    mean0 = torch.rand((c, h, w), generator=gen, device=dev, dtype=torch.float64)
+    var0 = torch.rand((c, h, w), generator=gen, device=dev, dtype=torch.float32) * 1e-4
+    flat = 0.5 + torch.rand((c, h, w), generator=gen, device=dev, dtype=torch.float32)
+    flat_std = 0.01 * flat
+    mean, var = mean0.clone(), var0.clone()
+
+    def step():  # in place; the values drift but the work per step is identical
+        ops.flatfield_correct(mean, var, flat, flat_std, input_is_variance=True, through_mean=True)
+
+    elapsed, kernel_ms = _timed_kernel(step, args)
+    q = c * h * w
+    # sums: value 8 + flat 4 read; apply: value 8 r + 8 w, variance 4 r + 4 w, flat 4, flat std 4
+    bytes_alg = q * ((8 + 4) + (16 + 8 + 4 + 4))
+    return {"metric": "MPix/s flat-field corrected (+variance term), 4096x4096x3", "unit": "MPix/s",
+            "value": round(h * w * args.steps / elapsed / 1e6, 1), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "8f-1: flat-field epilogue of the merge, 4096x4096x3, ct_flatfield_sums + ct_flatfield_apply"},
+            "roofline": _hbm_roofline(bytes_alg, kernel_ms)}
+
+
+def run_video(args, rank, world, dev):
+    """compute_video_mean_and_std, batches of 32 resident 1920x1080x3 uint16 frames, linearized in-kernel."""
+    from clair_torch_amd import ops
+    b, c, h, w = 32, 3, 1080, 1920
+    frames = torch.randint(0, 65536, (b, c, h, w), device=dev, dtype=torch.int32).to(torch.uint16)
+    lut = make_lut(dev)
+    mean = torch.zeros((c, h, w), device=dev, dtype=torch.float32)
+    m2 = torch.zeros_like(mean)
+    seen = [0]
+
+    def step():
+        ops.video_stats_batch(frames, mean, m2, seen[0], lut=lut, interp="linear")
+        seen[0] += b
+
+    elapsed, kernel_ms = _timed_kernel(step, args)
+    q = c * h * w
+    bytes_alg = q * (b * 2 + 16)  # every frame once + (mean, m2) float32 state read and written
+    return {"metric": "frames/s video mean/std (WBOMeanVar), 1920x1080x3 uint16, kernel-only", "unit": "frames/s",
+            "value": round(b * args.steps / elapsed, 1), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"8f-2: {b} resident 1920x1080x3 uint16 frames per batch, ct_video_stats_batch (LINEAR ICRF)"},
+            "roofline": _hbm_roofline(bytes_alg, kernel_ms)}
+
+
 def run_train(args, rank, world, dev):
     """C3: one train_icrf optimizer step (forward sums + LUT gradient + Adam) on a 64-exposure 2048x2048x3 stack."""
     from clair_torch_amd import ops
@@ -270,7 +342,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="merge", choices=["merge", "linearize", "train"])
+    ap.add_argument("--workload", default="merge", choices=["merge", "linearize", "train", "flatfield", "video"])
     ap.add_argument("--input", default="u16", choices=["u16", "f32"], help="merge: stack element type (default = C2)")
     ap.add_argument("--std", default="multiplier", choices=["multiplier", "explicit", "none"],
                     help="merge: uncertainty source (default = C2: sigma = 0.05 x derived in-kernel)")
@@ -301,7 +373,8 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
     from clair_torch_amd import _native
     _native.load()
-    fn = {"merge": run_merge, "linearize": run_linearize, "train": run_train}[args.workload]
+    fn = {"merge": run_merge, "linearize": run_linearize, "train": run_train, "flatfield": run_flatfield,
+          "video": run_video}[args.workload]
     out = fn(args, rank, world, dev)
     if rank == 0:
         sys.stdout.flush()

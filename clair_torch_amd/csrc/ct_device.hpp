@@ -201,4 +201,32 @@ struct TileMap {
     }
 };
 
+// ---- host: launch geometry -----------------------------------------------------------------------------------------
+// Number of compute units of the current device (cached); 256 on MI355X.
+static inline int compute_units()
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n_cu = v;
+        else
+            n_cu = 256;
+    }
+    return n_cu;
+}
+
+// Workgroups that can be resident on the whole device at once, for kernels that walk their work in a grid-stride
+// loop: a grid that is a multiple of this runs as full rounds of equal work.  (1026 long-running workgroups on 256
+// one-slot units run 4 full rounds plus 2 stragglers that cost a whole fifth round.)
+static inline int resident_workgroups(size_t lds_bytes, int block_threads)
+{
+    const size_t by_lds = lds_bytes ? (size_t)(160 * 1024) / lds_bytes : 64;
+    const size_t by_waves = (size_t)2048 / (size_t)block_threads;  // 32 wavefronts per unit
+    size_t slots = by_lds < by_waves ? by_lds : by_waves;
+    if (slots < 1) slots = 1;
+    return compute_units() * (int)slots;
+}
+
 }  // namespace ct

@@ -10,6 +10,7 @@
 //                       keeps the flush negligible).
 //
 // Roofline: HBM (sizeof(T) read + 4 or 8 B written per sample).  No reuse between workgroups, so no XCD remap.
+#include <algorithm>
 #include "ct_device.hpp"
 
 namespace ct {
@@ -243,14 +244,17 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
 template <int INTERP>
 static int bwd_launch(const BwdArgs &a, hipStream_t s)
 {
-    uint32_t gx = (a.q_count + kBlock - 1) / kBlock;
-    if (gx > 1024) gx = 1024;
     uint32_t gy = a.n_images;
     if (gy > 8) gy = 8;
     if (gy < 1) gy = 1;
     const size_t lut_bytes = (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP);
     const size_t lds = ((lut_bytes + 15) & ~(size_t)15) + sizeof(double) * (size_t)a.channels * a.n_points;
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+    // the whole grid is what the device holds at once: one round of equal grid-stride work, and as few histogram
+    // flushes (global atomics on C*L addresses) as possible
+    uint32_t gx = (a.q_count + kBlock - 1) / kBlock;
+    const uint32_t cap = std::max<uint32_t>(1u, (uint32_t)resident_workgroups(lds, kBlock) / gy);
+    if (gx > cap) gx = cap;
     hipLaunchKernelGGL((linearize_bwd_kernel<INTERP>), dim3(gx, gy), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }

@@ -396,6 +396,13 @@ struct PartnerEntry {  // 16 bytes: one broadcast ds_read_b128 per partner
 // 1024 threads (16 waves) per workgroup: at N = 64 the staged tile takes 90-130 KB of LDS, so one workgroup fits a
 // CU and it has to bring all the wavefronts the SIMDs get.
 constexpr int kBwdBlock = 1024;
+// Grid of the tile-walking pair kernels: every channel gets as many workgroups as the device holds at once, so the
+// launch runs as exactly C full rounds of equal work (measured on the backward: 7.7 ms against 9.6 ms with a grid
+// of 1026 on 256 one-slot units).
+static int workgroups_per_channel(size_t lds_bytes, int block, uint32_t tiles)
+{
+    return (int)std::min<uint32_t>(tiles, (uint32_t)resident_workgroups(lds_bytes, block));
+}
 
 // dL/dI_own contribution of one partner entry (lane = pixel).  OWN_IS_I: the own sample is the pair's first image.
 //   v = |q|, q = (I_i - r I_j) / (r I_j + eps)  [REL]  or  q = I_i - r I_j:
@@ -867,7 +874,7 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
     a.vec = vec_ok<T>(a, kBlock, 8);
     const size_t lds = lut_bytes + (size_t)a.n_images * a.row_pitch * entry;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
-    int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
+    const int per_chan = workgroups_per_channel(lds, kBlock, tiles);
     const int grid = per_chan * a.channels;
     // pairs are walked in chunks of 4 * 256 per launch
     for (int begin = 0; begin < a.n_pairs; begin += 4 * kBlock) {
@@ -935,7 +942,7 @@ static int bwd_launch_pairs(PairArgs a, hipStream_t s)
     a.vec = vec_ok<T>(a, kBwdBlock, 4);
     const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
-    int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
+    const int per_chan = workgroups_per_channel(lds, kBwdBlock, tiles);
     const int grid = per_chan * a.channels;
     if (tp == 128) {
         if (a.use_relative)
@@ -983,7 +990,7 @@ static int bwd_launch_once(PairArgs a, void *workspace, size_t workspace_bytes, 
     hipLaunchKernelGGL(pair_entries_kernel, dim3(a.channels), dim3(256), 0, s, a, first, table);
     const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
     const uint32_t tiles = (a.plane_local + tp - 1) / tp;
-    int per_chan = (int)std::min<uint32_t>(tiles, 1024u / (uint32_t)a.channels + 1);
+    const int per_chan = workgroups_per_channel(lds, kBwdBlock, tiles);
     const int grid = per_chan * a.channels;
     if (a.use_relative)
         hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, true>), dim3(grid), dim3(kBwdBlock), lds, s, a);

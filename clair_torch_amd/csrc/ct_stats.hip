@@ -6,8 +6,10 @@
 //   M = M_A + M_B + (W_A W_B / W)(mean_B - mean_A)^2,   mean = mean_A + (W_B / W)(mean_B - mean_A),   W = W_A + W_B
 // with unit weights (W_B = batch size), all in float32 like the reference's float32 frames.
 //
-// One thread owns V consecutive elements; the batch is read twice (mean pass, then the centred second moment exactly
-// as the reference forms it).  The second read of a packet comes from L2 for the batch sizes in use; HBM-bound.
+// One thread owns V consecutive elements.  The centred second moment needs the batch mean first, so the batch is
+// walked twice -- out of registers when the batch has at most 32 frames (video_stats_cached_kernel: every frame is
+// loaded and linearized exactly once, all loads in flight together), out of memory otherwise (video_stats_kernel).
+// Both form the sums in the reference's order, so they agree bit for bit.  HBM-bound.
 #include "ct_device.hpp"
 
 namespace ct {
@@ -28,6 +30,32 @@ template <typename T, int V>
 struct alignas(sizeof(T) * V) SPacket {
     T v[V];
 };
+
+// Merge of the batch statistics into the running state (statistics.py:245-251), shared by both kernels.
+template <int V>
+__device__ __forceinline__ void merge_state(const StatsArgs &a, uint32_t q0, const float (&mean_b)[V], const float (&m2)[V])
+{
+    const float WA = a.count_before, WB = (float)a.batch, W = WA + WB;
+    SPacket<float, V> mo, vo;
+    if (WA == 0.0f) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            mo.v[e] = mean_b[e];
+            vo.v[e] = m2[e];
+        }
+    } else {
+        const SPacket<float, V> ma = *reinterpret_cast<const SPacket<float, V> *>(a.mean_state + q0);
+        const SPacket<float, V> va = *reinterpret_cast<const SPacket<float, V> *>(a.m2_state + q0);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float delta = mean_b[e] - ma.v[e];
+            vo.v[e] = va.v[e] + m2[e] + (WA * WB / W) * (delta * delta);  // statistics.py:250
+            mo.v[e] = ma.v[e] + (WB / W) * delta;                          // statistics.py:251
+        }
+    }
+    *reinterpret_cast<SPacket<float, V> *>(a.mean_state + q0) = mo;
+    *reinterpret_cast<SPacket<float, V> *>(a.m2_state + q0) = vo;
+}
 
 template <typename T, int V, int INTERP>
 __global__ __launch_bounds__(kBlock) void video_stats_kernel(const StatsArgs a)
@@ -75,26 +103,63 @@ __global__ __launch_bounds__(kBlock) void video_stats_kernel(const StatsArgs a)
             m2[e] += dv * dv;
         }
     }
-    const float WA = a.count_before, WB = (float)B, W = WA + WB;
-    SPacket<float, V> mo, vo;
-    if (WA == 0.0f) {
+    merge_state<V>(a, q0, mean_b, m2);
+}
+
+// Batch of at most BMAX frames: the linearized values stay in registers between the mean and the m2 pass.
+template <typename T, int V, int INTERP, int BMAX>
+__global__ __launch_bounds__(kBlock) void video_stats_cached_kernel(const StatsArgs a)
+{
+    extern __shared__ __align__(16) char lds[];
+    constexpr bool kRanged = sizeof(T) != 4;
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    const int C = a.channels, L = a.n_points, B = a.batch;
+    stage_lut<INTERP>(lds, a.lut, C, L);
+    __syncthreads();
+    const uint32_t vec = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (vec * (uint32_t)V >= a.q_count) return;
+    const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
+    const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
+    int row_off[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            mo.v[e] = mean_b[e];
-            vo.v[e] = m2[e];
-        }
-    } else {
-        const SPacket<float, V> ma = *reinterpret_cast<const SPacket<float, V> *>(a.mean_state + q0);
-        const SPacket<float, V> va = *reinterpret_cast<const SPacket<float, V> *>(a.m2_state + q0);
+    for (int e = 0; e < V; ++e) {
+        int ch;
+        uint32_t qg;
+        a.tile.locate(q0 + e, ch, qg);
+        row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
+    }
+    const T *src = static_cast<const T *>(a.frames) + q0;
+    SPacket<T, V> raw[BMAX];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float delta = mean_b[e] - ma.v[e];
-            vo.v[e] = va.v[e] + m2[e] + (WA * WB / W) * (delta * delta);  // statistics.py:250
-            mo.v[e] = ma.v[e] + (WB / W) * delta;                          // statistics.py:251
+    for (int n = 0; n < BMAX; ++n)
+        if (n < B) raw[n] = *reinterpret_cast<const SPacket<T, V> *>(src + (int64_t)n * a.image_stride);
+    float xs[BMAX][V], sum[V], m2[V], mean_b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sum[e] = m2[e] = 0.0f;
+#pragma unroll
+    for (int n = 0; n < BMAX; ++n) {
+        if (n < B) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float d;
+                xs[n][e] = icrf_sample<INTERP, true, kRanged>(to_pixel<T>(raw[n].v[e], a.norm), lds + row_off[e], top, d);
+                sum[e] += xs[n][e];
+            }
         }
     }
-    *reinterpret_cast<SPacket<float, V> *>(a.mean_state + q0) = mo;
-    *reinterpret_cast<SPacket<float, V> *>(a.m2_state + q0) = vo;
+#pragma unroll
+    for (int e = 0; e < V; ++e) mean_b[e] = sum[e] / (float)B;  // torch.mean: float32 sum / count
+#pragma unroll
+    for (int n = 0; n < BMAX; ++n) {
+        if (n < B) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float dv = xs[n][e] - mean_b[e];
+                m2[e] += dv * dv;
+            }
+        }
+    }
+    merge_state<V>(a, q0, mean_b, m2);
 }
 
 template <typename T, int V, int INTERP>
@@ -104,7 +169,12 @@ static int stats_launch(const StatsArgs &a, hipStream_t s)
     const uint32_t vecs = a.q_count / V, grid = (vecs + kBlock - 1) / kBlock;
     const size_t lds = INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP);
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
-    hipLaunchKernelGGL((video_stats_kernel<T, V, INTERP>), dim3(grid), dim3(kBlock), lds, s, a);
+    if (a.batch <= 16)
+        hipLaunchKernelGGL((video_stats_cached_kernel<T, V, INTERP, 16>), dim3(grid), dim3(kBlock), lds, s, a);
+    else if (a.batch <= 32)
+        hipLaunchKernelGGL((video_stats_cached_kernel<T, V, INTERP, 32>), dim3(grid), dim3(kBlock), lds, s, a);
+    else
+        hipLaunchKernelGGL((video_stats_kernel<T, V, INTERP>), dim3(grid), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
@@ -123,7 +193,7 @@ static int stats_dispatch(const StatsArgs &a, int interp, hipStream_t s)
 template <typename T>
 static int stats_typed(StatsArgs a, uint32_t Q, int interp, hipStream_t s)
 {
-    constexpr int V = sizeof(T) == 4 ? 4 : 8;
+    constexpr int V = 4;  // 4 elements per thread: 32 frames x 4 values fit the register file
     auto aligned = [](const void *p, size_t b) { return (reinterpret_cast<uintptr_t>(p) % b) == 0; };
     const bool vec_ok = aligned(a.frames, sizeof(T) * V) && (a.image_stride % V) == 0 && aligned(a.mean_state, 4 * V) &&
                         aligned(a.m2_state, 4 * V);
