@@ -129,7 +129,7 @@ def run_merge(args, rank, world, dev):
         "config": {"workload": f"C2: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU, "
                                f"merge{'' if args.std == 'none' else '+uncertainty'} (LINEAR ICRF 3x256, Gaussian weights, "
                                f"sigma: {args.std}, float64 mean + float32 std out)",
-                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel<uint16, V=8, LINEAR, GAUSS, MULTIPLIER, FOLD, PF=2>",
+                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel (V=4 elements per thread, LINEAR, GAUSS, PF=2)",
                    "finite": bool(torch.isfinite(gathered).all())},
         "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
