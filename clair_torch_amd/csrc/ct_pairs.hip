@@ -7,14 +7,18 @@
 // weighted_mean_and_std over (H, W) (losses.py:70-108, general_functions.py:118-178).  The reference
 // materialises five (P, C, H, W) float64 tensors (P = O(N^2) pairs); here nothing pair-sized ever leaves the CU.
 //
-// Structure (both kernels): a workgroup walks tiles of TP pixels of ONE channel plane.  Phase 1 linearizes all N
-// samples of the tile once and parks (f(x), Gaussian weight with the validity in its sign[, LUT coordinate,
-// linearized std]) in LDS; phase 2 evaluates the pairs out of LDS.
-//   forward : thread <-> pair(s); each thread walks the tile's pixels and keeps its pairs' sums in registers
-//             (float32 inside a tile, float64 across tiles), one float64 atomic per sum per workgroup at the end.
-//   backward: wavefront <-> sample, lane <-> pixel; every lane sums dL/dI of its sample over the sample's partner
-//             list (uniform control flow, scalar pair data), then scatters into a (C, L) histogram in LDS
-//             (ds_add_f64 -- far cheaper than ds_add_f32 on gfx950 --, flushed with float64 global atomics at the end).
+// Structure (all kernels): a workgroup walks tiles of TP pixels of ONE channel plane.  Phase 1 linearizes all N
+// samples of the tile once and parks (f(x), Gaussian weight -- -inf when the sample is outside [lo, hi] --[, LUT
+// coordinate, linearized std]) in LDS; phase 2 evaluates the pairs out of LDS.
+//   forward       : thread <-> pair(s); each thread walks the tile's columns and keeps its pairs' sums in registers
+//                   (float32 inside a tile, float64 across tiles), one float64 atomic per sum per workgroup at the end.
+//   backward      : wavefront <-> sample i, lane <-> column; each pair is evaluated once from its first sample, the
+//                   partner's share goes to a (sample, column) float64 accumulator in LDS (ds_add_f64), and after a
+//                   barrier every (sample, column) is scattered into a (C, L) float64 histogram in LDS, flushed with
+//                   float64 global atomics at the end.  Pair constants come from a global table through scalar loads.
+//   backward, uncertainty-weighted loss: the older two-sided form (each pair evaluated from both samples, entries
+//                   in LDS), because its d(weight)/dI terms differ per side.
+// Grids are sized to whole rounds of what the device holds at once (resident_workgroups, ct_device.hpp).
 //
 // Arithmetic: the reference computes the residual in float64 because the ratio is float64.  Here
 // diff = I_i - I_j * r is formed with two float32 FMAs against r = r_hi + r_lo, which is exact to ~1 ulp of the
@@ -40,7 +44,7 @@ struct PairArgs {
     const double *smean;                                // (P, C) spatial means (uncertainty-weighted backward)
     double *lut_grad;                                   // (C, L) float64, +=
     const int32_t *first_g;                             // workspace: N + 1 offsets of the i-side entries per sample
-    const void *table_g;                                // workspace: (C, P) PartnerEntry, grouped by sample i
+    const void *table_g;                                // workspace: (C, P) OnceEntry, grouped by sample i
     int64_t image_stride;
     TileMap tile;
     uint32_t plane_local;
@@ -48,7 +52,7 @@ struct PairArgs {
     int32_t tp;           // pixels per tile (power of two, divides the workgroup size)
     int32_t tp_shift;     // log2(tp)
     int32_t vec;          // 1: planes are 4-element aligned -> vectorised, prefetching staging with permuted columns
-    int32_t val_offset;   // backward: byte offset of the staged tile in LDS (after LUT, histograms, entries, splits)
+    int32_t val_offset;   // backward: byte offset of the per-tile arrays in LDS (after LUT, histogram[, entries, splits])
     int32_t row_pitch;    // LDS row pitch in entries (tp + pad)
     int32_t pair_begin;   // first pair handled by this launch (forward)
     NormConst norm;
