@@ -43,7 +43,7 @@ struct PairArgs {
     const double *coef;                                 // (P, C)
     const double *smean;                                // (P, C) spatial means (uncertainty-weighted backward)
     double *lut_grad;                                   // (C, L) float64, +=
-    const int32_t *first_g;                             // workspace: N + 1 offsets of the i-side entries per sample
+    const int32_t *first_g;                             // workspace: N + 1 offsets of the i-side entries per sample, then C flags
     const void *table_g;                                // workspace: (C, P) OnceEntry, grouped by sample i
     int64_t image_stride;
     TileMap tile;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[s][k] = 0.0;
 
-    const int c = blockIdx.x % C;
+    const int c = (int)(blockIdx.x / (gridDim.x / (uint32_t)C));  // channel-major: a channel's workgroups are consecutive
     float cen[PPT];
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
     VecStager<T, INTERP, STD, false, 8> stager;
-    const uint32_t t_first = blockIdx.x / C;
+    const uint32_t t_first = blockIdx.x % gstep;
     if (a.vec && t_first < tiles)
         stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBlock);
     for (uint32_t t = t_first; t < tiles; t += gstep) {
@@ -482,13 +482,14 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
     float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
     float *lsdv = aux + (size_t)N * a.row_pitch;  // linearized std per sample (STD != none only)
     constexpr bool kUnc = STD != CT_STD_NONE;
-    const int c = blockIdx.x % C;
+    const int c = (int)(blockIdx.x / (gridDim.x / (uint32_t)C));  // channel-major: a channel's workgroups are consecutive
     stage_lut<INTERP>(lds, a.lut, C, L);
     for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
     // Partner entries, each sample's list stably partitioned into "own sample is i" entries followed by "own sample
     // is j" entries (split[n] = first j-side entry), so the pixel loop runs two select-free loops per sample.
     float *smv = reinterpret_cast<float *>(ent + n_ent);  // spatial mean per entry (uncertainty-weighted backward)
     int *split = reinterpret_cast<int *>(smv + (kUnc ? n_ent : 0));
+    int nonzero = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int e0 = a.part_off[n], e1 = a.part_off[n + 1];
         int n_i = 0;
@@ -506,18 +507,21 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
             pe.rlo = (float)(r - (double)pe.rhi);
             const float cf = (float)a.coef[(int64_t)p * C + c];
             pe.cf = (kUnc || own_is_i) ? cf : -cf * pe.rhi;
+            nonzero |= cf != 0.0f ? 1 : 0;
             const int at = own_is_i ? at_i++ : at_j++;
             ent[at] = pe;
             if constexpr (kUnc) smv[at] = (float)a.smean[(int64_t)p * C + c];
         }
     }
+    // no upstream gradient for this channel (loss[c].backward() of another channel): the whole workgroup leaves
+    if (!__syncthreads_or(nonzero)) return;
     // the wavefront index is uniform: readfirstlane lets the sample / partner loops run on the scalar unit
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int nwaves = kBwdBlock >> 6;
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
     VecStager<T, INTERP, STD, true, 4> stager;
-    const uint32_t t_first = blockIdx.x / C;
+    const uint32_t t_first = blockIdx.x % gstep;
     if (a.vec && t_first < tiles)
         stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBwdBlock);
     for (uint32_t t = t_first; t < tiles; t += gstep) {
@@ -660,7 +664,9 @@ __device__ __forceinline__ void once_term(const OnceEntry &pe, float2 own, float
     gj = pe.cfr * uj;
 }
 
-// Fills the workspace of the pair-once backward: first[N + 1] and, per channel, the i-side partner entries grouped by
+// Fills the workspace of the pair-once backward: first[N + 1], active[C] (does the channel have any non-zero upstream
+// coefficient -- loss[c].backward() of the reference's per-channel loop touches one channel at a time, and the main
+// kernel's workgroups of the other channels return at once) and, per channel, the i-side partner entries grouped by
 // sample (one workgroup per channel).  The entries are wavefront-uniform in the main kernel, which therefore reads
 // them with scalar loads (SGPR operands, no LDS traffic, no VALU moves).
 __global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int32_t *first, OnceEntry *table)
@@ -685,6 +691,7 @@ __global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int
     if (c == 0)
         for (int n = threadIdx.x; n <= N; n += blockDim.x) first[n] = sfirst[n];
     OnceEntry *tab = table + (size_t)c * a.n_pairs;
+    int nonzero = 0;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         int at = sfirst[n];
         for (int e = a.part_off[n]; e < a.part_off[n + 1]; ++e) {
@@ -697,9 +704,12 @@ __global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int
             pe.rlo = (float)(r - (double)pe.rhi);
             pe.cf = (float)a.coef[(int64_t)p * C + c];
             pe.cfr = -pe.cf * pe.rhi;
+            nonzero |= pe.cf != 0.0f ? 1 : 0;
             tab[at++] = pe;
         }
     }
+    const int any = __syncthreads_or(nonzero);
+    if (threadIdx.x == 0) first[N + 1 + c] = any;
 }
 
 template <typename T, int INTERP, bool REL>
@@ -714,12 +724,13 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
     float2 *val = reinterpret_cast<float2 *>(gacc + (size_t)N * a.row_pitch);
     float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
     int *colrow = reinterpret_cast<int *>(aux + (size_t)N * a.row_pitch);  // histogram row offset (row * L) per column
-    const int c = blockIdx.x % C;
+    const int c = (int)(blockIdx.x / (gridDim.x / (uint32_t)C));  // channel-major: a channel's workgroups are consecutive
     // constant address space + uniform index = scalar loads (s_load_dwordx4 into SGPRs); the tables were written by
     // the preceding launch and are read-only here
     typedef const int32_t __attribute__((address_space(4))) *ConstInts;
     ConstInts first = (ConstInts)(uintptr_t)a.first_g;
     ConstWords ent = (ConstWords)(uintptr_t)(static_cast<const OnceEntry *>(a.table_g) + (size_t)c * a.n_pairs);
+    if (first[N + 1 + c] == 0) return;  // no upstream gradient for this channel (uniform: the whole workgroup leaves)
     stage_lut<INTERP>(lds, a.lut, C, L);
     for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -727,7 +738,7 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
     VecStager<T, INTERP, CT_STD_NONE, true, 4> stager;
-    const uint32_t t_first = blockIdx.x / C;
+    const uint32_t t_first = blockIdx.x % gstep;
     if (a.vec && t_first < tiles)
         stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBwdBlock);
     const int col = min(lane, a.tp - 1);
@@ -964,7 +975,7 @@ static int bwd_launch_pairs(PairArgs a, hipStream_t s)
 
 static size_t once_workspace_bytes(int n_images, int n_pairs, int channels)
 {
-    return (((size_t)(n_images + 1) * 4 + 31) & ~(size_t)31) + (size_t)channels * n_pairs * sizeof(OnceEntry);
+    return (((size_t)(n_images + 1 + channels) * 4 + 31) & ~(size_t)31) + (size_t)channels * n_pairs * sizeof(OnceEntry);
 }
 
 template <typename T, int INTERP>
@@ -988,7 +999,7 @@ static int bwd_launch_once(PairArgs a, void *workspace, size_t workspace_bytes, 
     a.vec = vec_ok<T>(a, kBwdBlock, 4);
     int32_t *first = static_cast<int32_t *>(workspace);
     OnceEntry *table = reinterpret_cast<OnceEntry *>(static_cast<char *>(workspace) +
-                                                     (((size_t)(a.n_images + 1) * 4 + 31) & ~(size_t)31));
+                                                     (((size_t)(a.n_images + 1 + a.channels) * 4 + 31) & ~(size_t)31));
     a.first_g = first;
     a.table_g = table;
     hipLaunchKernelGGL(pair_entries_kernel, dim3(a.channels), dim3(256), 0, s, a, first, table);

@@ -76,7 +76,9 @@ int main(int argc, char **argv)
     for (int c = 0; c < C; ++c)
         for (int k = 0; k < L; ++k) lut[(size_t)c * L + k] = powf((float)k / (L - 1), 2.2f + 0.2f * c);
     std::vector<double> coef((size_t)P * C);
-    for (size_t k = 0; k < coef.size(); ++k) coef[k] = 1e-7 * (1.0 + (k % 7));
+    const int only_channel = argc > 3 ? atoi(argv[3]) : -1;  // >= 0: upstream gradient for that channel only
+    for (size_t k = 0; k < coef.size(); ++k)
+        coef[k] = (only_channel < 0 || (int)(k % C) == only_channel) ? 1e-7 * (1.0 + (k % 7)) : 0.0;
     int *d_i, *d_j, *d_off, *d_ps, *d_pp;
     double *d_r, *d_sums, *d_coef, *d_grad;
     float *d_lut;
