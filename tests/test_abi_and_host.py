@@ -329,3 +329,21 @@ def test_icrf_txt_io_layouts_and_errors(tmp_path):
     assert torch.allclose(load_icrf_txt(out), curve)
     save_icrf_txt(curve, out, ChannelOrder.RGB, DimensionOrder.BCS)
     assert torch.allclose(load_icrf_txt(out, ChannelOrder.RGB, DimensionOrder.BCS), curve)
+
+
+def test_custom_collate_returns_views_of_equally_spaced_images():
+    """Batches of an in-memory stack alias it (no 2 x stack-size copy per batch); anything irregular is stacked."""
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    x = torch.arange(5 * 3 * 4 * 6, dtype=torch.float32).reshape(5, 3, 4, 6)
+    ds = StackDataset(x, [1.0, 2.0, 3.0, 4.0, 5.0], stds=0.1 * x)
+    _, vals, stds, meta = custom_collate([ds[i] for i in (3, 1, 2)])  # sorted by exposure: images 1, 2, 3
+    assert vals.data_ptr() == x[1].data_ptr() and torch.equal(vals, x[1:4])
+    assert stds.data_ptr() == ds.stds[1].data_ptr() and stds.stride() == vals.stride()
+    assert meta["exposure_time"].tolist() == [2.0, 3.0, 4.0]
+    _, vals, _, _ = custom_collate([ds[i] for i in (0, 2, 4)])  # equally spaced: one strided view
+    assert vals.data_ptr() == x.data_ptr() and vals.stride(0) == 2 * x.stride(0) and torch.equal(vals, x[0::2])
+    _, vals, _, _ = custom_collate([ds[i] for i in (0, 1, 3)])  # irregular spacing: a stacked copy
+    assert vals.data_ptr() != x.data_ptr() and torch.equal(vals, x[[0, 1, 3]])
+    rev = StackDataset(x, [5.0, 4.0, 3.0, 2.0, 1.0])  # sorting reverses the storage order: a copy
+    _, vals, _, _ = custom_collate([rev[i] for i in (0, 1, 2)])
+    assert torch.equal(vals, x[[2, 1, 0]])
