@@ -16,8 +16,8 @@
 //                   partner's share goes to a (sample, column) float64 accumulator in LDS (ds_add_f64), and after a
 //                   barrier every (sample, column) is scattered into a (C, L) float64 histogram in LDS, flushed with
 //                   float64 global atomics at the end.  Pair constants come from a global table through scalar loads.
-//   backward, uncertainty-weighted loss: the older two-sided form (each pair evaluated from both samples, entries
-//                   in LDS), because its d(weight)/dI terms differ per side.
+//                   The uncertainty-weighted loss (weights depending on the LUT through err) uses the same kernel with the
+//                   linearized stds staged as a fourth per-column array.
 // Grids are sized to whole rounds of what the device holds at once (resident_workgroups, ct_device.hpp).
 //
 // Arithmetic: the reference computes the residual in float64 because the ratio is float64.  Here
@@ -380,26 +380,20 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
 }
 
 // ---- backward ------------------------------------------------------------------------------------
-// coef[p][c] = dL/d(spatial mean_pc) / max(sum w m, 1e-8): the weights do not depend on the LUT when
-// use_uncertainty_weighting is off, so d mean / d I = w m / den * d v / d I.
-// One partner-list entry, resolved once per workgroup into LDS so the inner loop has no dependent scalar loads:
-// partner sample's LDS row, which side of the pair this sample is on, the ratio split in two floats, and the
-// upstream coefficient of that pair for this workgroup's channel.
-struct PartnerEntry {  // 16 bytes: one broadcast ds_read_b128 per partner
-    int row;    // partner sample's row in the staged tile, as a BYTE offset into val[] (row * row_pitch * 8)
-    float rhi, rlo;  // exposure ratio split in two floats
-    float cf;   // upstream coefficient; without uncertainty weighting the side's constant factor is folded in
-};
-
-// Two backward kernels share this section.  pair_bwd_kernel evaluates each pair from both of its samples (own-side
-// gradient in a register, no LDS writes in the inner loop); it serves the uncertainty-weighted loss, whose extra
-// d(weight)/dI terms differ per side.  pair_bwd_once_kernel (further down) evaluates each pair once and is used
-// otherwise.  History: the first pair-once attempt accumulated the partner side with ds_add_f32 and was 2-3.5x slower
-// -- the float32 LDS atomic costs ~190 cycles per wave-instruction on gfx950 for any address pattern, where
-// ds_add_f64 costs ~9 (lane-linear) to ~20 (random); see tools/lds_atomic_rates.hip.
-// 1024 threads (16 waves) per workgroup: at N = 64 the staged tile takes 90-130 KB of LDS, so one workgroup fits a
+// coef[p][c] = dL/d(spatial mean_pc) / max(sum w m, 1e-8).  Without uncertainty weighting the weights do not depend
+// on the LUT and d mean / d I = w m / den * d v / d I.  With it (STD != CT_STD_NONE: weights w = 1/(err + 1e-6) + gauss,
+// losses.py:93-100) the weights depend on the LUT through err when the loss is relative:
+//   d mean = sum m [w dv + (v - mean) dw] / D.
+// Every pair is evaluated ONCE, from its first sample (wavefront <-> sample i, lane <-> tile column): the shared part
+// of the evaluation (residual, 1/es, mask, sign, err) serves both sides.  The i-side term stays in a register; the
+// j-side term goes to a per-tile (sample, column) float64 accumulator in LDS with ds_add_f64 on lane-linear addresses
+// (~9 cycles per wave-instruction; the float32 LDS atomic costs ~190 for ANY address pattern on gfx950, which is why
+// an earlier float32 attempt at this design lost to evaluating every pair from both sides; tools/lds_atomic_rates.hip).
+// After a barrier every (sample, column) entry is scattered into the (C, L) float64 histogram.
+// 1024 threads (16 waves) per workgroup: at N = 64 the per-tile arrays take ~100 KB of LDS, so one workgroup fits a
 // CU and it has to bring all the wavefronts the SIMDs get.
 constexpr int kBwdBlock = 1024;
+
 // Grid of the tile-walking pair kernels: every channel gets as many workgroups as the device holds at once, so the
 // launch runs as exactly C full rounds of equal work (measured on the backward: 7.7 ms against 9.6 ms with a grid
 // of 1026 on 256 one-slot units).
@@ -408,216 +402,6 @@ static int workgroups_per_channel(size_t lds_bytes, int block, uint32_t tiles)
     return (int)std::min<uint32_t>(tiles, (uint32_t)resident_workgroups(lds_bytes, block));
 }
 
-// dL/dI_own contribution of one partner entry (lane = pixel).  OWN_IS_I: the own sample is the pair's first image.
-//   v = |q|, q = (I_i - r I_j) / (r I_j + eps)  [REL]  or  q = I_i - r I_j:
-//   dq/dI_i = 1/es,  dq/dI_j = -r (I_i + eps)/es^2   [REL];   dq/dI_i = 1, dq/dI_j = -r   [absolute]
-// and dv = sign(q) dq.  Without uncertainty weighting the entry's cf already carries the side's constant factor
-// (cf for i, -cf r for j), the mask comes from the -inf encoded weight, and sign(q)/es is sign(diff)/|es|.
-template <bool REL, bool UNC, bool OWN_IS_I>
-__device__ __forceinline__ void partner_term(float &G, const PartnerEntry &pe, float sm, float2 own, float own_sd,
-                                             float2 oth, float oth_sd)
-{
-    const float Ii = OWN_IS_I ? own.x : oth.x, Ij = OWN_IS_I ? oth.x : own.x;
-    const float d1 = __builtin_fmaf(-Ij, pe.rhi, Ii);
-    const float diff = __builtin_fmaf(-Ij, pe.rlo, d1);
-    const float ws = own.y + oth.y;  // Gaussian pair weight, -inf unless both samples are valid
-    if constexpr (!UNC) {
-        const float wm = fmaxf(ws, 0.0f);
-        const float sg = sign_of(diff);
-        if constexpr (REL) {
-            const float inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Ij, pe.rhi, 1e-6f));
-            float t = wm * fabsf(inv_es);
-            if constexpr (!OWN_IS_I) t *= (Ii + 1e-6f) * inv_es;
-            G = __builtin_fmaf(pe.cf, t * sg, G);
-        } else {
-            G = __builtin_fmaf(pe.cf, wm * sg, G);
-        }
-    } else {
-        const bool mk = ws >= 0.0f;
-        float wt = fmaxf(ws, 0.0f), dv, extra = 0.0f;  // extra = (v - mean) dw/dI_own; finite even when masked
-        const float si = OWN_IS_I ? own_sd : oth_sd, sj = OWN_IS_I ? oth_sd : own_sd;
-        if constexpr (REL) {
-            const float inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Ij, pe.rhi, 1e-6f));
-            const float q = diff * inv_es;
-            const float sg = sign_of(q);
-            dv = OWN_IS_I ? sg * inv_es : -sg * pe.rhi * (Ii + 1e-6f) * inv_es * inv_es;
-            const float inv_ijs = __builtin_amdgcn_rcpf(fmaxf(Ij, 1e-6f));
-            const float t1 = si * inv_es, t2 = (Ii * sj) * inv_es * inv_ijs;  // losses.py:55-57
-            const float err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
-            const float uw = __builtin_amdgcn_rcpf(err + 1e-6f);
-            wt += uw;
-            float derr;
-            if constexpr (OWN_IS_I)  // d err / d I_i: only t2 depends on I_i
-                derr = t2 * (sj * inv_es * inv_ijs);
-            else  // d err / d I_j: both terms through (e + eps), t2 also through clamp(I_j, eps)
-                derr = -(t1 * t1 * pe.rhi * inv_es + t2 * t2 * (pe.rhi * inv_es + (Ij >= 1e-6f ? inv_ijs : 0.0f)));
-            derr *= __builtin_amdgcn_rcpf(err);
-            extra = (fabsf(q) - sm) * (-uw * uw * derr);
-        } else {  // losses.py:61: the error does not depend on the LUT
-            const float sg = sign_of(diff);
-            dv = OWN_IS_I ? sg : -sg * pe.rhi;
-            const float rs = pe.rhi * sj;
-            wt += __builtin_amdgcn_rcpf(sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
-        }
-        G = __builtin_fmaf(mk ? pe.cf : 0.0f, __builtin_fmaf(wt, dv, extra), G);
-    }
-}
-
-// STD != CT_STD_NONE selects the uncertainty-weighted loss (weights w = 1/(err + 1e-6) + gauss, losses.py:93-100),
-// whose weights depend on the LUT through err when the loss is relative:  d mean = sum m [w dv + (v - mean) dw] / D.
-// PPL = pixels per lane (tile = 64 * PPL pixels): with two, one partner entry serves two evaluations.
-template <typename T, int INTERP, bool REL, int STD, int PPL>
-__global__ __launch_bounds__(kBwdBlock) void pair_bwd_kernel(const PairArgs a)
-{
-    extern __shared__ __align__(16) char lds[];
-    constexpr int kEntry = lut_entry_bytes(INTERP);
-    const int C = a.channels, L = a.n_points, N = a.n_images;
-    const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
-    // (C, L) float64 histogram: ds_add_f64 costs ~20 cycles per wave-instruction on random bins where ds_add_f32 costs
-    // ~190 on ANY address pattern (tools/lds_atomic_rates.hip), so the gradient is scattered in float64 directly.
-    double *hist64 = reinterpret_cast<double *>(lds + lut_bytes);
-    PartnerEntry *ent = reinterpret_cast<PartnerEntry *>(hist64 + C * L);
-    const int n_ent = 2 * a.n_pairs;
-    float2 *val = reinterpret_cast<float2 *>(lds + a.val_offset);
-    float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
-    float *lsdv = aux + (size_t)N * a.row_pitch;  // linearized std per sample (STD != none only)
-    constexpr bool kUnc = STD != CT_STD_NONE;
-    const int c = (int)(blockIdx.x / (gridDim.x / (uint32_t)C));  // channel-major: a channel's workgroups are consecutive
-    stage_lut<INTERP>(lds, a.lut, C, L);
-    for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
-    // Partner entries, each sample's list stably partitioned into "own sample is i" entries followed by "own sample
-    // is j" entries (split[n] = first j-side entry), so the pixel loop runs two select-free loops per sample.
-    float *smv = reinterpret_cast<float *>(ent + n_ent);  // spatial mean per entry (uncertainty-weighted backward)
-    int *split = reinterpret_cast<int *>(smv + (kUnc ? n_ent : 0));
-    int nonzero = 0;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const int e0 = a.part_off[n], e1 = a.part_off[n + 1];
-        int n_i = 0;
-        for (int e = e0; e < e1; ++e) n_i += a.part_pair[e] >= 0 ? 1 : 0;
-        split[n] = e0 + n_i;
-        int at_i = e0, at_j = e0 + n_i;
-        for (int e = e0; e < e1; ++e) {
-            const int code = a.part_pair[e];
-            const bool own_is_i = code >= 0;
-            const int p = own_is_i ? code : ~code;
-            const double r = a.ratio[p];
-            PartnerEntry pe;
-            pe.row = a.part_sample[e] * a.row_pitch * (int)sizeof(float2);
-            pe.rhi = (float)r;
-            pe.rlo = (float)(r - (double)pe.rhi);
-            const float cf = (float)a.coef[(int64_t)p * C + c];
-            pe.cf = (kUnc || own_is_i) ? cf : -cf * pe.rhi;
-            nonzero |= cf != 0.0f ? 1 : 0;
-            const int at = own_is_i ? at_i++ : at_j++;
-            ent[at] = pe;
-            if constexpr (kUnc) smv[at] = (float)a.smean[(int64_t)p * C + c];
-        }
-    }
-    // no upstream gradient for this channel (loss[c].backward() of another channel): the whole workgroup leaves
-    if (!__syncthreads_or(nonzero)) return;
-    // the wavefront index is uniform: readfirstlane lets the sample / partner loops run on the scalar unit
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int nwaves = kBwdBlock >> 6;
-    const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
-    const uint32_t gstep = gridDim.x / C;
-    VecStager<T, INTERP, STD, true, 4> stager;
-    const uint32_t t_first = blockIdx.x % gstep;
-    if (a.vec && t_first < tiles)
-        stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBwdBlock);
-    for (uint32_t t = t_first; t < tiles; t += gstep) {
-        const uint32_t pix0 = t * a.tp;
-        const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
-        lds_barrier();
-        if (a.vec) {
-            stager.commit(a, lds, val, aux, lsdv, c, pix0, npix, kBwdBlock);
-            const uint32_t tn = t + gstep;
-            if (tn < tiles) stager.issue(a, c, tn * a.tp, (int)min((uint32_t)a.tp, a.plane_local - tn * a.tp), kBwdBlock);
-        } else {
-            stage_tile<T, INTERP, STD, true>(a, lds, val, aux, c, pix0, npix, kBwdBlock, lsdv);
-        }
-        lds_barrier();
-        const int col = min(lane, a.tp - 1);  // 32-pixel tiles (very large N): the upper half-wave idles in bounds
-        const char *valb = reinterpret_cast<const char *>(val + col);
-        const char *lsdb = reinterpret_cast<const char *>(lsdv + col);
-        for (int n = wave; n < N; n += nwaves) {
-            float2 own[PPL];
-            float own_sd[PPL], G[PPL];
-#pragma unroll
-            for (int k = 0; k < PPL; ++k) {
-                own[k] = val[n * a.row_pitch + col + 64 * k];
-                own_sd[k] = kUnc ? lsdv[n * a.row_pitch + col + 64 * k] : 0.0f;
-                G[k] = 0.0f;
-            }
-            const int e0 = a.part_off[n], em = __builtin_amdgcn_readfirstlane(split[n]), e1 = a.part_off[n + 1];
-#pragma unroll 4
-            for (int e = e0; e < em; ++e) {
-                const PartnerEntry pe = ent[e];
-                const float sm = kUnc ? smv[e] : 0.0f;
-#pragma unroll
-                for (int k = 0; k < PPL; ++k) {
-                    const float2 oth = *reinterpret_cast<const float2 *>(valb + pe.row + 512 * k);
-                    const float oth_sd = kUnc ? *reinterpret_cast<const float *>(lsdb + (pe.row >> 1) + 256 * k) : 0.0f;
-                    partner_term<REL, kUnc, true>(G[k], pe, sm, own[k], own_sd[k], oth, oth_sd);
-                }
-            }
-#pragma unroll 4
-            for (int e = em; e < e1; ++e) {
-                const PartnerEntry pe = ent[e];
-                const float sm = kUnc ? smv[e] : 0.0f;
-#pragma unroll
-                for (int k = 0; k < PPL; ++k) {
-                    const float2 oth = *reinterpret_cast<const float2 *>(valb + pe.row + 512 * k);
-                    const float oth_sd = kUnc ? *reinterpret_cast<const float *>(lsdb + (pe.row >> 1) + 256 * k) : 0.0f;
-                    partner_term<REL, kUnc, false>(G[k], pe, sm, own[k], own_sd[k], oth, oth_sd);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PPL; ++k) {
-                const int colk = lane + 64 * k, px = pixel_of_column(a, colk);
-                if (colk < a.tp && px < npix && G[k] != 0.0f) {
-                    const uint32_t qg = (uint32_t)c * (a.plane_local + a.tile.chan_skip) + a.tile.base + pix0 + (uint32_t)px;
-                    double *hrow = hist64 + lut_row<INTERP>(qg, c, C) * L;
-                    const float s = aux[n * a.row_pitch + colk];
-                    const float Gk = G[k];
-                    if constexpr (INTERP == CT_INTERP_LOOKUP) {
-                        atomicAdd(&hrow[(int)rintf(s)], (double)Gk);
-                    } else {
-                        const float fl = floorf(s);
-                        const int i0 = (int)fl;
-                        const float tt = s - fl;
-                        if constexpr (INTERP == CT_INTERP_LINEAR) {
-                            const int i1 = i0 + 1 < L ? i0 + 1 : L - 1;
-                            atomicAdd(&hrow[i0], (double)(Gk * (1.0f - tt)));
-                            atomicAdd(&hrow[i1], (double)(Gk * tt));
-                        } else {
-                            const float t2 = tt * tt, t3 = t2 * tt;
-                            const float w0 = -0.5f * t3 + t2 - 0.5f * tt, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
-                            const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * tt, w3 = 0.5f * t3 - 0.5f * t2;
-                            const int im = i0 > 0 ? i0 - 1 : 0, i1 = i0 + 1 < L ? i0 + 1 : L - 1,
-                                      i2 = i0 + 2 < L ? i0 + 2 : L - 1;
-                            atomicAdd(&hrow[im], (double)(Gk * w0));
-                            atomicAdd(&hrow[i0], (double)(Gk * w1));
-                            atomicAdd(&hrow[i1], (double)(Gk * w2));
-                            atomicAdd(&hrow[i2], (double)(Gk * w3));
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < C * L; k += blockDim.x)
-        if (hist64[k] != 0.0) atomicAdd(&a.lut_grad[k], hist64[k]);
-}
-
-// ---- backward, every pair evaluated once (no uncertainty weighting) -------------------------------------------
-// Same mapping (wavefront <-> sample i, lane <-> tile column), but only the "own sample is i" entries are walked: the
-// shared part of the evaluation (residual, 1/es, mask, sign) serves both sides of the pair.  The i-side term stays in
-// a register; the j-side term goes to a per-tile (sample, column) float64 accumulator in LDS with ds_add_f64 on
-// lane-linear addresses (~9 cycles per wave-instruction, tools/lds_atomic_rates.hip -- the float32 LDS atomic costs
-// ~190, which is why an earlier float32 attempt at this design lost).  After a barrier every (sample, column) entry
-// is scattered into the (C, L) histogram.  ~14 VALU instructions per pair-pixel against 11 + 14 when each side is
-// evaluated separately.
 // Entry of the pair-once backward's global partner table: 32 bytes, read with one s_load_dwordx8 (uniform index,
 // constant address space) so every field arrives in an SGPR.
 struct OnceEntry {
@@ -625,7 +409,8 @@ struct OnceEntry {
     float rhi, rlo;  // exposure ratio split in two floats
     float cf;        // upstream coefficient of the pair for this channel (i-side factor)
     float cfr;       // -cf * r (j-side factor)
-    int pad[3];
+    float sm;        // spatial mean of the pair for this channel (uncertainty-weighted backward)
+    int pad[2];
 };
 typedef int32_t Words8 __attribute__((ext_vector_type(8)));
 typedef const Words8 __attribute__((address_space(4))) *ConstWords;
@@ -638,6 +423,7 @@ __device__ __forceinline__ OnceEntry load_entry(ConstWords table, int k)
     pe.rlo = __int_as_float(w.s2);
     pe.cf = __int_as_float(w.s3);
     pe.cfr = __int_as_float(w.s4);
+    pe.sm = __int_as_float(w.s5);
     return pe;
 }
 
@@ -662,6 +448,48 @@ __device__ __forceinline__ void once_term(const OnceEntry &pe, float2 own, float
     const float uj = REL ? ui * qj : ui;
     Gi = __builtin_fmaf(pe.cf, ui, Gi);
     gj = pe.cfr * uj;
+}
+
+// The same for the uncertainty-weighted loss: w = gauss + 1/(err + 1e-6), err from the linearized stds s_i, s_j
+// (losses.py:50-63); relative loss: d err / d I_i goes through t2 only, d err / d I_j through (e + eps) in both terms
+// and through clamp(I_j, eps) in t2.  Both sides share 1/es, 1/clamp(I_j), err, 1/err and the (v - mean) dw factor.
+template <bool REL>
+__device__ __forceinline__ void once_term_unc(const OnceEntry &pe, float2 own, float own_sd, float2 oth, float oth_sd,
+                                              float &Gi, float &gj)
+{
+    const float Ii = own.x, Ij = oth.x, si = own_sd, sj = oth_sd;
+    const float d1 = __builtin_fmaf(-Ij, pe.rhi, Ii);
+    const float diff = __builtin_fmaf(-Ij, pe.rlo, d1);
+    const float ws = own.y + oth.y;  // Gaussian pair weight, -inf unless both samples are valid
+    float wt = fmaxf(ws, 0.0f);      // finite even when masked
+    float dvi, dvj, ei = 0.0f, ej = 0.0f;
+    if constexpr (REL) {
+        const float inv_es = __builtin_amdgcn_rcpf(__builtin_fmaf(Ij, pe.rhi, 1e-6f));
+        const float q = diff * inv_es;
+        const float sg = sign_of(q);
+        dvi = sg * inv_es;
+        dvj = -sg * pe.rhi * (Ii + 1e-6f) * inv_es * inv_es;
+        const float inv_ijs = __builtin_amdgcn_rcpf(fmaxf(Ij, 1e-6f));
+        const float t1 = si * inv_es, u2 = sj * inv_es * inv_ijs, t2 = Ii * u2;  // losses.py:55-57
+        const float err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
+        const float uw = __builtin_amdgcn_rcpf(err + 1e-6f);
+        wt += uw;
+        const float rinv = pe.rhi * inv_es;
+        const float derr_i = t2 * u2;
+        const float derr_j = -(t1 * t1 * rinv + t2 * t2 * (rinv + (Ij >= 1e-6f ? inv_ijs : 0.0f)));
+        const float c1 = (fabsf(q) - pe.sm) * (-uw * uw) * __builtin_amdgcn_rcpf(err);  // (v - mean) dw/derr / err
+        ei = c1 * derr_i;
+        ej = c1 * derr_j;
+    } else {  // losses.py:61: the error does not depend on the LUT
+        const float sg = sign_of(diff);
+        dvi = sg;
+        dvj = -sg * pe.rhi;
+        const float rs = pe.rhi * sj;
+        wt += __builtin_amdgcn_rcpf(sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
+    }
+    const float cfm = ws >= 0.0f ? pe.cf : 0.0f;
+    Gi = __builtin_fmaf(cfm, __builtin_fmaf(wt, dvi, ei), Gi);
+    gj = cfm * __builtin_fmaf(wt, dvj, ej);
 }
 
 // Fills the workspace of the pair-once backward: first[N + 1], active[C] (does the channel have any non-zero upstream
@@ -704,6 +532,7 @@ __global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int
             pe.rlo = (float)(r - (double)pe.rhi);
             pe.cf = (float)a.coef[(int64_t)p * C + c];
             pe.cfr = -pe.cf * pe.rhi;
+            pe.sm = a.smean ? (float)a.smean[(int64_t)p * C + c] : 0.0f;
             nonzero |= pe.cf != 0.0f ? 1 : 0;
             tab[at++] = pe;
         }
@@ -712,7 +541,7 @@ __global__ __launch_bounds__(256) void pair_entries_kernel(const PairArgs a, int
     if (threadIdx.x == 0) first[N + 1 + c] = any;
 }
 
-template <typename T, int INTERP, bool REL>
+template <typename T, int INTERP, bool REL, int STD>
 __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs a)
 {
     extern __shared__ __align__(16) char lds[];
@@ -722,8 +551,10 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
     double *hist64 = reinterpret_cast<double *>(lds + lut_bytes);
     double *gacc = reinterpret_cast<double *>(lds + a.val_offset);         // (N, row_pitch) dL/dI accumulators
     float2 *val = reinterpret_cast<float2 *>(gacc + (size_t)N * a.row_pitch);
+    constexpr bool kUnc = STD != CT_STD_NONE;
     float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
-    int *colrow = reinterpret_cast<int *>(aux + (size_t)N * a.row_pitch);  // histogram row offset (row * L) per column
+    float *lsdv = aux + (size_t)N * a.row_pitch;  // linearized std per (sample, column), uncertainty weighting only
+    int *colrow = reinterpret_cast<int *>(lsdv + (kUnc ? (size_t)N * a.row_pitch : 0));  // histogram row offset per column
     const int c = (int)(blockIdx.x / (gridDim.x / (uint32_t)C));  // channel-major: a channel's workgroups are consecutive
     // constant address space + uniform index = scalar loads (s_load_dwordx4 into SGPRs); the tables were written by
     // the preceding launch and are read-only here
@@ -737,7 +568,7 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
     constexpr int nwaves = kBwdBlock >> 6;
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
-    VecStager<T, INTERP, CT_STD_NONE, true, 4> stager;
+    VecStager<T, INTERP, STD, true, 4> stager;
     const uint32_t t_first = blockIdx.x % gstep;
     if (a.vec && t_first < tiles)
         stager.issue(a, c, t_first * a.tp, (int)min((uint32_t)a.tp, a.plane_local - t_first * a.tp), kBwdBlock);
@@ -747,11 +578,11 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
         const int npix = (int)min((uint32_t)a.tp, a.plane_local - pix0);
         lds_barrier();  // the previous tile's scatter is done
         if (a.vec) {
-            stager.commit(a, lds, val, aux, nullptr, c, pix0, npix, kBwdBlock);
+            stager.commit(a, lds, val, aux, lsdv, c, pix0, npix, kBwdBlock);
             const uint32_t tn = t + gstep;
             if (tn < tiles) stager.issue(a, c, tn * a.tp, (int)min((uint32_t)a.tp, a.plane_local - tn * a.tp), kBwdBlock);
         } else {
-            stage_tile<T, INTERP, CT_STD_NONE, true>(a, lds, val, aux, c, pix0, npix, kBwdBlock, nullptr);
+            stage_tile<T, INTERP, STD, true>(a, lds, val, aux, c, pix0, npix, kBwdBlock, lsdv);
         }
         for (int k = threadIdx.x; k < N * a.row_pitch; k += blockDim.x) gacc[k] = 0.0;
         if ((int)threadIdx.x < a.tp) {  // the LUT row of a column depends on the pixel only (models/base.py:173-176)
@@ -762,9 +593,11 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
         lds_barrier();
         {   // uniform control flow throughout: with 32-column tiles the upper half-wave works on a masked copy
             const char *valb = reinterpret_cast<const char *>(val + col);
+            const char *lsdb = reinterpret_cast<const char *>(lsdv + col);
             char *gaccb = reinterpret_cast<char *>(gacc + col);
             for (int n = wave; n < N; n += nwaves) {
                 float2 own = val[n * a.row_pitch + col];
+                const float own_sd = kUnc ? lsdv[n * a.row_pitch + col] : 0.0f;
                 if (lane >= a.tp) own.y = -INFINITY;
                 float Gi = 0.0f;
                 const int e0 = first[n], e1 = first[n + 1];
@@ -775,13 +608,21 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
                 for (; e + kGroup <= e1; e += kGroup) {
                     OnceEntry pe[kGroup];
                     float2 oth[kGroup];
-                    float gj[kGroup];
+                    float osd[kGroup], gj[kGroup];
 #pragma unroll
                     for (int u = 0; u < kGroup; ++u) pe[u] = load_entry(ent, e + u);
 #pragma unroll
-                    for (int u = 0; u < kGroup; ++u) oth[u] = *reinterpret_cast<const float2 *>(valb + pe[u].row);
+                    for (int u = 0; u < kGroup; ++u) {
+                        oth[u] = *reinterpret_cast<const float2 *>(valb + pe[u].row);
+                        if constexpr (kUnc) osd[u] = *reinterpret_cast<const float *>(lsdb + (pe[u].row >> 1));
+                    }
 #pragma unroll
-                    for (int u = 0; u < kGroup; ++u) once_term<REL>(pe[u], own, oth[u], Gi, gj[u]);
+                    for (int u = 0; u < kGroup; ++u) {
+                        if constexpr (kUnc)
+                            once_term_unc<REL>(pe[u], own, own_sd, oth[u], osd[u], Gi, gj[u]);
+                        else
+                            once_term<REL>(pe[u], own, oth[u], Gi, gj[u]);
+                    }
 #pragma unroll
                     for (int u = 0; u < kGroup; ++u)
                         atomicAdd(reinterpret_cast<double *>(gaccb + pe[u].row), (double)gj[u]);
@@ -790,7 +631,10 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
                     const OnceEntry pe = load_entry(ent, e);
                     const float2 oth = *reinterpret_cast<const float2 *>(valb + pe.row);
                     float gj;
-                    once_term<REL>(pe, own, oth, Gi, gj);
+                    if constexpr (kUnc)
+                        once_term_unc<REL>(pe, own, own_sd, oth, *reinterpret_cast<const float *>(lsdb + (pe.row >> 1)), Gi, gj);
+                    else
+                        once_term<REL>(pe, own, oth, Gi, gj);
                     atomicAdd(reinterpret_cast<double *>(gaccb + pe.row), (double)gj);
                 }
                 atomicAdd(&gacc[n * a.row_pitch + col], (double)Gi);
@@ -894,14 +738,9 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
     // pairs are walked in chunks of 4 * 256 per launch
     for (int begin = 0; begin < a.n_pairs; begin += 4 * kBlock) {
         a.pair_begin = begin;
-        const int left = a.n_pairs - begin;
-        int rc;
-        if (left <= kBlock)
-            rc = fwd_launch_level<T, INTERP, STD, 1>(a, lds, grid, level, s);
-        else if (left <= 2 * kBlock)
-            rc = fwd_launch_level<T, INTERP, STD, 2>(a, lds, grid, level, s);
-        else
-            rc = fwd_launch_level<T, INTERP, STD, 4>(a, lds, grid, level, s);
+        // always four pair slots per thread (slots past the end of the list are skipped): one instantiation instead of
+        // three keeps the build time of this file in check
+        const int rc = fwd_launch_level<T, INTERP, STD, 4>(a, lds, grid, level, s);
         if (rc != CT_OK) return rc;
     }
     return CT_OK;
@@ -938,47 +777,12 @@ static int fwd_dispatch(const PairArgs &a, int interp, int std_mode, int level, 
     return CT_ERR_INVALID_ARGUMENT;
 }
 
-template <typename T, int INTERP, int STD>
-static int bwd_launch_pairs(PairArgs a, hipStream_t s)
-{
-    const size_t lut_bytes = ((size_t)a.channels * a.n_points * lut_entry_bytes(INTERP) + 15) & ~(size_t)15;
-    const size_t cl = (size_t)a.channels * a.n_points;
-    // LUT | float64 histogram | partner entries [| spatial means] | per-sample split | staged tile
-    const size_t per_entry = sizeof(PartnerEntry) + (STD == CT_STD_NONE ? 0 : 4);
-    const size_t fixed = (lut_bytes + cl * 8 + (size_t)2 * a.n_pairs * per_entry +
-                          (size_t)a.n_images * 4 + 15) & ~(size_t)15;
-    const int per_sample = STD == CT_STD_NONE ? 12 : 16;
-    const int tp = pick_tile(a.n_images, fixed, per_sample, 128);
-    if (tp == 0) return CT_ERR_TOO_LARGE;
-    a.tp = tp;
-    a.tp_shift = tp == 128 ? 7 : (tp == 64 ? 6 : 5);
-    a.val_offset = (int32_t)fixed;
-    a.row_pitch = tp + 1;
-    a.vec = vec_ok<T>(a, kBwdBlock, 4);
-    const size_t lds = fixed + (size_t)a.n_images * a.row_pitch * per_sample;
-    const uint32_t tiles = (a.plane_local + tp - 1) / tp;
-    const int per_chan = workgroups_per_channel(lds, kBwdBlock, tiles);
-    const int grid = per_chan * a.channels;
-    if (tp == 128) {
-        if (a.use_relative)
-            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, true, STD, 2>), dim3(grid), dim3(kBwdBlock), lds, s, a);
-        else
-            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, false, STD, 2>), dim3(grid), dim3(kBwdBlock), lds, s, a);
-    } else {
-        if (a.use_relative)
-            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, true, STD, 1>), dim3(grid), dim3(kBwdBlock), lds, s, a);
-        else
-            hipLaunchKernelGGL((pair_bwd_kernel<T, INTERP, false, STD, 1>), dim3(grid), dim3(kBwdBlock), lds, s, a);
-    }
-    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
-}
-
 static size_t once_workspace_bytes(int n_images, int n_pairs, int channels)
 {
     return (((size_t)(n_images + 1 + channels) * 4 + 31) & ~(size_t)31) + (size_t)channels * n_pairs * sizeof(OnceEntry);
 }
 
-template <typename T, int INTERP>
+template <typename T, int INTERP, int STD>
 static int bwd_launch_once(PairArgs a, void *workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.n_images > 1024) return CT_ERR_TOO_LARGE;
@@ -989,7 +793,8 @@ static int bwd_launch_once(PairArgs a, void *workspace, size_t workspace_bytes, 
     const size_t cl = (size_t)a.channels * a.n_points;
     // LUT | float64 histogram | (N, pitch) float64 accumulators | staged tile
     const size_t fixed = ((lut_bytes + cl * 8 + 15) & ~(size_t)15) + 256;  // + colrow[tp] at the very end
-    const int per_sample = 8 + 12;  // accumulator + (value, weight) + LUT coordinate, per tile column (+ 256 B of rows)
+    // accumulator + (value, weight) + LUT coordinate [+ linearized std], per tile column (+ 256 B of rows)
+    const int per_sample = 8 + 12 + (STD == CT_STD_NONE ? 0 : 4);
     const int tp = pick_tile(a.n_images, fixed, per_sample, 64);
     if (tp == 0) return CT_ERR_TOO_LARGE;
     a.tp = tp;
@@ -1008,9 +813,9 @@ static int bwd_launch_once(PairArgs a, void *workspace, size_t workspace_bytes, 
     const int per_chan = workgroups_per_channel(lds, kBwdBlock, tiles);
     const int grid = per_chan * a.channels;
     if (a.use_relative)
-        hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, true>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+        hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, true, STD>), dim3(grid), dim3(kBwdBlock), lds, s, a);
     else
-        hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, false>), dim3(grid), dim3(kBwdBlock), lds, s, a);
+        hipLaunchKernelGGL((pair_bwd_once_kernel<T, INTERP, false, STD>), dim3(grid), dim3(kBwdBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
@@ -1018,13 +823,16 @@ template <typename T, int INTERP>
 static int bwd_dispatch_std(const PairArgs &a, int std_mode, void *ws, size_t ws_bytes, hipStream_t s)
 {
 #ifdef CT_PAIRS_MINIMAL
-    return std_mode == CT_STD_NONE ? bwd_launch_once<T, INTERP>(a, ws, ws_bytes, s) : CT_ERR_UNSUPPORTED;
+    return std_mode == CT_STD_NONE ? bwd_launch_once<T, INTERP, CT_STD_NONE>(a, ws, ws_bytes, s) : CT_ERR_UNSUPPORTED;
 #endif
+    if constexpr (INTERP == CT_INTERP_LOOKUP) {  // with uncertainties LOOKUP has no gradient path (rejected by the caller)
+        return std_mode == CT_STD_NONE ? bwd_launch_once<T, INTERP, CT_STD_NONE>(a, ws, ws_bytes, s) : CT_ERR_NO_GRADIENT_PATH;
+    }
     switch (std_mode) {
-        case CT_STD_NONE: return bwd_launch_once<T, INTERP>(a, ws, ws_bytes, s);
-        case CT_STD_CONSTANT: return bwd_launch_pairs<T, INTERP, CT_STD_CONSTANT>(a, s);
-        case CT_STD_MULTIPLIER: return bwd_launch_pairs<T, INTERP, CT_STD_MULTIPLIER>(a, s);
-        case CT_STD_EXPLICIT: return bwd_launch_pairs<T, INTERP, CT_STD_EXPLICIT>(a, s);
+        case CT_STD_NONE: return bwd_launch_once<T, INTERP, CT_STD_NONE>(a, ws, ws_bytes, s);
+        case CT_STD_CONSTANT: return bwd_launch_once<T, INTERP, CT_STD_CONSTANT>(a, ws, ws_bytes, s);
+        case CT_STD_MULTIPLIER: return bwd_launch_once<T, INTERP, CT_STD_MULTIPLIER>(a, ws, ws_bytes, s);
+        case CT_STD_EXPLICIT: return bwd_launch_once<T, INTERP, CT_STD_EXPLICIT>(a, ws, ws_bytes, s);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
