@@ -347,3 +347,26 @@ def test_custom_collate_returns_views_of_equally_spaced_images():
     rev = StackDataset(x, [5.0, 4.0, 3.0, 2.0, 1.0])  # sorting reverses the storage order: a copy
     _, vals, _, _ = custom_collate([rev[i] for i in (0, 1, 2)])
     assert torch.equal(vals, x[[2, 1, 0]])
+
+
+def test_pair_backward_workspace_contract(lib):
+    """ct_pair_residual_bwd validates its caller-owned workspace before anything is launched."""
+    from clair_torch_amd import _native as nv
+    n, p, c = 6, 9, 3
+    need = lib.ct_pair_residual_bwd_workspace(n, p, c)
+    assert need >= (n + 1 + c) * 4 + p * c * 32 and need % 32 == 0
+    assert lib.ct_pair_residual_bwd_workspace(-1, p, c) == 0
+    g = nv.Geometry(channels=c, h_tile=8, width=8, h_global=8, row_offset=0, image_stride=c * 64)
+    lut = nv.Icrf(lut_dev=0x1000, n_points=256, interp=nv.INTERP_LINEAR)
+    prm = nv.PairParams(lower=0.0, upper=1.0, weight_scale=10.0, use_relative=1, use_uncertainty_weighting=0,
+                        std_mode=nv.STD_NONE, std_value=0.0)
+    fake = ctypes.c_void_p(0x1000)  # never dereferenced: validation fails first
+
+    def call(ws, ws_bytes):
+        return lib.ct_pair_residual_bwd(fake, nv.DTYPE_F32, 1.0, n, ctypes.byref(g), None, ctypes.byref(lut), fake, p,
+                                        fake, fake, fake, ctypes.byref(prm), fake, None, fake, ws, ws_bytes, None)
+
+    assert call(None, 0) == -1                              # no workspace
+    assert call(ctypes.c_void_p(0x2000), need - 1) == -1    # too small
+    assert call(ctypes.c_void_p(0x2004), need) == -1        # not 32-byte aligned
+    assert call(ctypes.c_void_p(0x2000), -5) == -1
