@@ -301,6 +301,9 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
     }
     const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
     const uint32_t gstep = gridDim.x / C;
+    // v_sqrt_f32 (1 ulp) instead of sqrtf's correctly rounded expansion (~12 instructions) for the residual's error:
+    // the tolerance of these statistics is 1e-5; the uncertainty weight is switched by a 0/1 factor, not a branch
+    const float unc_on = a.use_unc_weight ? 1.0f : 0.0f;
     VecStager<T, INTERP, STD, false, 8> stager;
     const uint32_t t_first = blockIdx.x % gstep;
     if (a.vec && t_first < tiles)
@@ -346,12 +349,12 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
                         const float ijs = fmaxf(Bv.x, 1e-6f);
                         const float t1 = si * inv_es;
                         const float t2 = (A.x * sj) * inv_es * __builtin_amdgcn_rcpf(ijs);
-                        err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
+                        err = __builtin_amdgcn_sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
                     } else {  // losses.py:61
                         const float rs = rhi[s] * sj;
-                        err = sqrtf(__builtin_fmaf(si, si, rs * rs));
+                        err = __builtin_amdgcn_sqrtf(__builtin_fmaf(si, si, rs * rs));
                     }
-                    if (a.use_unc_weight) wt += __builtin_amdgcn_rcpf(err + 1e-6f);  // losses.py:96
+                    wt = __builtin_fmaf(unc_on, __builtin_amdgcn_rcpf(err + 1e-6f), wt);  // losses.py:96 (unc_on is 0 or 1)
                 }
                 const float wm = fmaxf(wt, 0.0f);
                 f[0] += wm;
@@ -471,7 +474,7 @@ __device__ __forceinline__ void once_term_unc(const OnceEntry &pe, float2 own, f
         dvj = -sg * pe.rhi * (Ii + 1e-6f) * inv_es * inv_es;
         const float inv_ijs = __builtin_amdgcn_rcpf(fmaxf(Ij, 1e-6f));
         const float t1 = si * inv_es, u2 = sj * inv_es * inv_ijs, t2 = Ii * u2;  // losses.py:55-57
-        const float err = sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
+        const float err = __builtin_amdgcn_sqrtf(__builtin_fmaf(t1, t1, __builtin_fmaf(t2, t2, 1e-6f)));
         const float uw = __builtin_amdgcn_rcpf(err + 1e-6f);
         wt += uw;
         const float rinv = pe.rhi * inv_es;
@@ -485,7 +488,7 @@ __device__ __forceinline__ void once_term_unc(const OnceEntry &pe, float2 own, f
         dvi = sg;
         dvj = -sg * pe.rhi;
         const float rs = pe.rhi * sj;
-        wt += __builtin_amdgcn_rcpf(sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
+        wt += __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(__builtin_fmaf(si, si, rs * rs)) + 1e-6f);
     }
     const float cfm = ws >= 0.0f ? pe.cf : 0.0f;
     Gi = __builtin_fmaf(cfm, __builtin_fmaf(wt, dvi, ei), Gi);
