@@ -91,12 +91,36 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
 
     int row_off[V];  // byte offset of each element's LUT row inside the LDS table
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
+    if (a.tile.layout == CT_LAYOUT_NCHW) {
+        // planar input: one division and one modulo per packet; the next element's global index is one further (plus
+        // the rows of the other bands when the packet runs into the next channel plane), so its row follows by an add
+        // and a conditional subtract
         int ch;
         uint32_t qg;
-        a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
-        row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
+        a.tile.locate(q0, ch, qg);
+        uint32_t off = q0 - (uint32_t)ch * a.tile.plane_local;
+        int r = (int)(qg % (uint32_t)C);
+        const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            row_off[e] = (INTERP == CT_INTERP_LOOKUP ? ch : r) * L * kEntry;
+            int inc = 1;
+            if (++off == a.tile.plane_local) {
+                off = 0;
+                ++ch;
+                inc += skip_mod;
+            }
+            r += inc;
+            r = r >= C ? r - C : r;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int ch;
+            uint32_t qg;
+            a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
+            row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
+        }
     }
 
     float W[V], Swy[V];
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
             if constexpr (kHasStd) a.var_state[q] = var;
         }
         mean_o[e] = mean;
-        std_o[e] = sqrtf(var);
+        std_o[e] = __builtin_amdgcn_sqrtf(var);
     }
     if (finalize && a.tile.layout != CT_LAYOUT_NCHW) {
         // interleaved input: the V elements of this thread belong to different planes -> element-wise stores
