@@ -171,7 +171,7 @@ def run_linearize(args, rank, world, dev):
             "config": {"workload": f"C4: {args.frames} resident 1920x1080x3 uint16 frames per launch, ct_linearize_std"},
             "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": None}}
+                         "traffic": measured_traffic("linearize_c4") if args.frames == 64 else None}}
 
 
 def _timed_kernel(step, args):
@@ -293,7 +293,7 @@ def _train_roofline(n_pairs, elements, seconds):
     flops = 2.0 * 12.0 * n_pairs * elements
     achieved = flops / seconds / 1e12
     return {"bound": "valu", "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(achieved / 157.3, 4), "traffic": None}
+            "frac": round(achieved / 157.3, 4), "traffic": measured_traffic("train_c3") if (n_pairs, elements) == (888, 3 * 2048 * 2048) else None}
 
 
 def measured_traffic(key):
