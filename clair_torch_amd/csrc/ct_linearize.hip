@@ -74,9 +74,13 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
                 if constexpr (STD == CT_STD_EXPLICIT) sigma = sp.v[e];
                 if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;  // datasets/base.py:133
                 if constexpr (STD == CT_STD_CONSTANT) sigma = a.std_value;
-                // linearization.py:106,132: sqrt((grad * std) ** 2); sqrt of a correctly rounded square is |.|
-                const float gs = dfdx * sigma;
-                so.v[e] = STD == CT_STD_NONE ? 0.0f : sqrtf(gs * gs);
+                // linearization.py:106,132: sqrt((grad * std) ** 2).  In binary floating point the correctly rounded
+                // square root of a correctly rounded square is |.| exactly unless the square underflows, so the
+                // ~12-instruction sqrtf expansion only runs for 0 < |gs| < 1e-18 (practically never; wave-uniform skip)
+                const float gs = dfdx * sigma, ags = fabsf(gs);
+                float sd = ags;
+                if (ags < 1e-18f && ags != 0.0f) sd = sqrtf(gs * gs);
+                so.v[e] = STD == CT_STD_NONE ? 0.0f : sd;
             }
         }
         if (a.tile.layout != CT_LAYOUT_NCHW) {  // interleaved input -> planar outputs, element-wise stores
