@@ -161,6 +161,39 @@ def test_merge_tiles_equal_whole(dev):
     assert not torch.equal(m_bad, mean[:, 7:48])
 
 
+@pytest.mark.parametrize("c,h,w", [(4, 5, 3), (2, 4, 3), (4, 3, 5)])
+@pytest.mark.parametrize("dtype", ["u16", "f32"])
+def test_merge_packets_crossing_channel_planes(dev, c, h, w, dtype):
+    """Planes whose size is not a multiple of the packet while the image is: packets straddle channel planes (and,
+    in a row band, skip the other bands' rows) -- the per-packet LUT-row bookkeeping must follow.  Whole image against
+    the oracle, every row band bit-identical to the whole."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(c * 100 + h * 10 + w)
+    n = 6
+    t = 0.002 * 2.0 ** (np.arange(n) / 2.0)
+    lut = np.stack([np.linspace(0, 1, 64, dtype=np.float32) ** np.float32(1.8 + 0.3 * k) for k in range(c)])
+    if dtype == "f32":
+        x = rng.random((n, c, h, w), dtype=np.float32)
+        stack = torch.from_numpy(x).to(dev)
+    else:
+        codes = rng.integers(0, 65536, size=(n, c, h, w)).astype(np.uint16)
+        x = oc.normalize_codes(codes)
+        stack = torch.from_numpy(codes).to(dev)
+    sd = (0.05 * x).astype(np.float32)
+    lut_d = torch.from_numpy(lut).to(dev)
+    for mode in ("linear", "catmull", "lookup"):
+        kw = dict(lut=lut_d, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+        mean, std = ops.hdr_merge_batch(stack, torch.from_numpy(t), **kw)
+        mean_o, std_o = oc.hdr_merge(x, sd, t, lut, mode, True, [n])
+        assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"{mode} mean")
+        assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, elem_tol=5e-5, what=f"{mode} std")
+        for r0, r1 in ((0, 1), (1, h), (0, h - 1)):
+            m_t, s_t = ops.hdr_merge_batch(stack[:, :, r0:r1].contiguous(), torch.from_numpy(t),
+                                           tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw)
+            assert torch.equal(m_t, mean[:, r0:r1]) and torch.equal(s_t, std[:, r0:r1]), (mode, r0, r1)
+
+
 def test_merge_full_size_properties(dev):
     """BASELINE config C2 size (32 x 4096 x 4096 x 3 uint16): size-independent properties instead of an oracle run.
     (1) exposure-scale covariance: multiplying every exposure time by 2 halves mean and std exactly (power of two);
