@@ -94,3 +94,51 @@ extern "C" int ct_index_constants(float max_code, int n_points, float *hi, float
     *lo = cached_lo;
     return cached_rc;
 }
+
+// merge_pivot_kernel addresses the LINEAR table by the interval index computed from the raw code in integer arithmetic:
+// floor(u / step) with step = max_code / (L-1), as (u * M) >> 32 with M = ceil(2^32 / step) < 2^24 (one
+// v_mul_hi_u32_u24), or the code itself when step == 1.  Allowed only if step is an integer and the result equals the
+// reference's float32 interval floor(fl(fl(u / max_code) * (L-1))) (clair_torch/models/base.py:166-168) for EVERY code;
+// checked exhaustively here and cached per (max_code, L).  *index_mul = 0 means "the code is the index".
+extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step)
+{
+    static std::mutex mu;
+    static float cached_max = 0.0f, cached_step = 0.0f;
+    static uint32_t cached_mul = 0;
+    static int cached_L = 0, cached_rc = CT_ERR_UNSUPPORTED;
+    if (!(max_code >= 1.0f) || max_code > 65535.0f || floorf(max_code) != max_code || n_points < 2)
+        return CT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached_max != max_code || cached_L != n_points) {
+        const int maxc = (int)max_code, top = n_points - 1;
+        int rc = CT_OK;
+        uint32_t mul = 0;
+        float st = 0.0f;
+        if (top > maxc || maxc % top != 0) {
+            rc = CT_ERR_UNSUPPORTED;
+        } else {
+            const uint32_t istep = (uint32_t)(maxc / top);
+            st = (float)istep;
+            if (istep > 1) {
+                const uint64_t m = ((1ull << 32) + istep - 1) / istep;
+                if (m >= (1ull << 24)) rc = CT_ERR_UNSUPPORTED;
+                mul = (uint32_t)m;
+            }
+            for (int u = 0; rc == CT_OK && u <= maxc; ++u) {
+                volatile float x = (float)u / max_code;
+                volatile float s_ref = x * (float)top;
+                const uint32_t ref = (uint32_t)floorf(s_ref);
+                const uint32_t got = istep > 1 ? (uint32_t)(((uint64_t)(uint32_t)u * mul) >> 32) : (uint32_t)u;
+                if (ref != got || got > (uint32_t)top) rc = CT_ERR_UNSUPPORTED;
+            }
+        }
+        cached_max = max_code;
+        cached_L = n_points;
+        cached_mul = mul;
+        cached_step = st;
+        cached_rc = rc;
+    }
+    *index_mul = cached_mul;
+    *step = cached_step;
+    return cached_rc;
+}

@@ -22,8 +22,11 @@
 // Roofline: HBM.  Algorithmic bytes per output element = B * sizeof(T) (+ 4 B with an explicit std stack)
 // read + 12 written (float64 mean + float32 std).  No MFMA: this is a gather/reduce, not a contraction.
 #include "ct_device.hpp"
+#include <type_traits>
 
 namespace ct {
+
+#define GLOBAL_AS __attribute__((address_space(1)))  // global memory (keeps laundered addresses off the flat path)
 
 struct MergeArgs {
     const void *stack;
@@ -347,6 +350,479 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     }
 }
 
+// =====================================================================================================================
+// Round 2 kernel for raw integer codes (LINEAR / no model): single-precision moments about a per-pixel pivot.
+//
+// Why: the kernel above is VALU-bound on the 2 B/sample headline form (profiles/r01_merge_c2_sq_counters.md), and 45 %
+// of its loop is the float64 moments plus the float -> index conversions; another 20 % of all VALU work sat outside
+// the loop (per-workgroup LUT staging with integer divides, three IEEE float64 divisions per output element).  Here:
+//   * moments about a pivot p ~ m_b:   c_n = b_n - p a_n = w'_n sigma_n (y_n - p) + w_n y'_n sigma_n   (float32)
+//       sum (alpha a_n + beta b_n)^2 = beta^2 Scc + 2 beta kappa Sac + kappa^2 Saa,   kappa = gamma - beta (m_b - p),
+//       gamma = (W_A / Wt^2)(m_b - mean_A).  With |m_b - p| << m_b the expansion no longer cancels (for LINEAR
+//       |a_n (m_b - p)| <= 13.6 |m_b - p| / m_b times the y' term), so float32 sums carry it.  The pivot is the running
+//       mean of the earlier batches, or for a first batch the sample of the middle exposure.  Every output element
+//       checks its own conditioning (sum of |terms| against the result); a wavefront with an ill-conditioned element
+//       runs the batch a second time about the now known mean (explicit fallback, exact to float32 rounding).
+//   * the batch mean is accumulated about the same pivot: sum w (y - p), mean = p + ..., in float64 only at the end;
+//   * LUT entry {g[i], (g[i+1]-g[i]) / step, i * step, (g[i+1]-g[i]) * (L-1) * kk / K} indexed by floor(code / step)
+//     = mul_hi_u24(code, M) (one SDWA instruction on the packed codes, host-verified for every code against the
+//     reference's float32 index); f = g + slope * (code - i * step): no float coordinate, no fract, no float -> int;
+//   * persistent workgroups: the table and 1/t are staged once per workgroup, not once per 1024 elements;
+//   * the epilogue has no float64 division (one v_rcp_f32 + Newton step, shared by the mean and the variance).
+// LOOKUP (b = a y exactly: the whole variance is the cancelling part) and CATMULL stay on the float64 kernel above.
+// Element e of a packet of raw codes as float, and its LUT interval, straight from the packed dwords: on uint16 both
+// are one SDWA instruction (v_cvt_f32_u32 / v_mul_hi_u32_u24 with a word select), so the codes are never unpacked.
+// (Left to itself LLVM unpacks with v_and / v_lshrrev first because the code has two users, and turns
+// ((code * M) >> 32) << 4 into a 64-bit alignbit + and + add.)
+template <int WORD>
+__device__ __forceinline__ float word_to_float(uint32_t dw)
+{
+    float r;
+    if constexpr (WORD == 0)
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(dw));
+    else
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(dw));
+    return r;
+}
+template <int WORD>
+__device__ __forceinline__ uint32_t word_mul_hi_u24(uint32_t dw, uint32_t mul)
+{
+    uint32_t r;
+    if constexpr (WORD == 0)
+        asm("v_mul_hi_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+            : "=v"(r) : "v"(dw), "s"(mul));
+    else
+        asm("v_mul_hi_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+            : "=v"(r) : "v"(dw), "s"(mul));
+    return r;
+}
+template <typename T, int V, int E>
+__device__ __forceinline__ float code_to_float(const Packet<T, V> &pk)
+{
+    if constexpr (sizeof(T) == 2 && V % 2 == 0)
+        return word_to_float<E & 1>(reinterpret_cast<const uint32_t *>(&pk)[E >> 1]);
+    else
+        return (float)pk.v[E];
+}
+// floor(code * (L-1) / max_code) (uint16, by the host-verified multiplier) or the code itself (uint8)
+template <typename T, int V, int E>
+__device__ __forceinline__ uint32_t code_to_interval(const Packet<T, V> &pk, uint32_t mul)
+{
+    if constexpr (sizeof(T) == 2 && V % 2 == 0)
+        return word_mul_hi_u24<E & 1>(reinterpret_cast<const uint32_t *>(&pk)[E >> 1], mul);
+    else if constexpr (sizeof(T) == 2)
+        return (uint32_t)(((uint64_t)pk.v[E] * (uint64_t)(mul & 0xffffffu)) >> 32);
+    else
+        return pk.v[E];
+}
+
+// One packet from global memory at (wave-uniform 64-bit base) + (32-bit per-thread byte offset).
+template <typename P>
+__device__ __forceinline__ P load_global(uint64_t base, uint32_t offset)
+{
+    const GLOBAL_AS char *ptr = reinterpret_cast<const GLOBAL_AS char *>(base) + offset;
+    P out;
+    if constexpr (sizeof(P) == 1) {
+        const uint8_t v = *reinterpret_cast<const GLOBAL_AS uint8_t *>(ptr);
+        __builtin_memcpy(&out, &v, sizeof(P));
+    } else if constexpr (sizeof(P) == 2) {
+        const uint16_t v = *reinterpret_cast<const GLOBAL_AS uint16_t *>(ptr);
+        __builtin_memcpy(&out, &v, sizeof(P));
+    } else if constexpr (sizeof(P) == 4) {
+        const uint32_t v = *reinterpret_cast<const GLOBAL_AS uint32_t *>(ptr);
+        __builtin_memcpy(&out, &v, sizeof(P));
+    } else {
+        static_assert(sizeof(P) % 4 == 0, "wide packets are whole dwords");
+        typedef uint32_t vec_t __attribute__((ext_vector_type(sizeof(P) / 4)));
+        const vec_t v = *reinterpret_cast<const GLOBAL_AS vec_t *>(ptr);
+        __builtin_memcpy(&out, &v, sizeof(P));
+    }
+    return out;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+struct PivotArgs {
+    uint32_t index_mul;  // floor(code * (L-1) / max_code) == (code * index_mul) >> 32 for every code (uint16 only)
+    float step;          // max_code / (L-1), an integer
+    uint32_t n_tiles;    // tiles of kBlock * V elements
+    int32_t probe;       // exposure whose sample seeds the pivot of a first batch
+    unsigned long long *retry_count;  // diagnostics: wavefronts that ran the fallback pass (may be NULL)
+};
+
+constexpr float kPivotCondLimit = 8.0f;  // sum |terms| / result above which a wavefront repeats the batch about the mean
+
+#ifndef CT_PIVOT_KERNEL_ATTR
+#define CT_PIVOT_KERNEL_ATTR
+#endif
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST>
+__global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kernel(const MergeArgs a, const PivotArgs x)
+{
+    extern __shared__ __align__(16) char lds[];
+    static_assert(sizeof(T) != 4, "raw integer codes only");
+    static_assert(INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_NONE, "LOOKUP / CATMULL use merge_kernel");
+    constexpr bool kLut = INTERP == CT_INTERP_LINEAR;
+    constexpr bool kDirect = sizeof(T) == 1;  // uint8: L - 1 == max_code, the code is the index
+    constexpr bool kHasStd = STD != CT_STD_NONE;
+    constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
+    const int C = a.channels, L = a.n_points, B = a.batch;
+    const int lut_bytes = kLut ? C * L * 16 : 0;
+    float *inv_t = reinterpret_cast<float *>(lds + lut_bytes);
+    const float top = kLut ? (float)(L - 1) : 1.0f;
+    const float kk = sqrtf(a.weight_scale * 1.4426950408889634f);
+    const float K = -2.0f * a.weight_scale;
+    const float ce = kGauss ? kk * top / K : top;  // chain factor of the y' term, without 1 / t_n
+
+    if constexpr (kLut) {
+        const int total = C * L;
+        const float inv_step = 1.0f / x.step;
+        for (int k = threadIdx.x; k < total; k += kBlock) {
+            const int r = k / L, i = k - r * L;
+            const float *row = a.lut + (size_t)r * L;
+            const float g0 = row[i], dg = row[i + 1 < L ? i + 1 : L - 1] - g0;  // the reference backward's g1 - g0
+            reinterpret_cast<float4 *>(lds)[k] = make_float4(g0, dg * inv_step, (float)i * x.step, dg * ce);
+        }
+    }
+    for (int n = threadIdx.x; n < B; n += kBlock) inv_t[n] = (float)(1.0 / a.exposure[n]);
+    __syncthreads();  // the only barrier: everything below is per wavefront
+
+    constexpr bool first = FIRST;  // CT_MERGE_FIRST_BATCH: no state is read, and none is carried through the loop
+    const bool finalize = a.flags & CT_MERGE_FINALIZE;
+    const bool keep_state = a.mean_state != nullptr;
+    const bool planar = a.tile.layout == CT_LAYOUT_NCHW;
+    const float dk_mul = kk * a.inv_max_code, dk_add = -0.5f * kk;
+    float fsf = 1.0f;  // scale of the folded moments back to true units
+    if constexpr (kGauss) fsf = K / kk;
+    if constexpr (STD == CT_STD_CONSTANT) fsf *= a.std_value;
+    if constexpr (STD == CT_STD_MULTIPLIER) fsf *= a.std_value * a.inv_max_code;
+    const float sv2 = fsf * fsf;
+    const uint32_t index_mul = x.index_mul & 0xffffffu;
+
+    for (uint32_t tile = blockIdx.x; tile < x.n_tiles; tile += gridDim.x) {
+        const uint32_t vec = tile * (uint32_t)kBlock + threadIdx.x;
+        if (vec * (uint32_t)V >= a.q_count) continue;  // ragged last tile (no barrier below: lanes may leave)
+        const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
+
+        int row_off[V];  // byte offset of each element's LUT row inside the LDS table
+        if constexpr (kLut) {
+            if (planar) {
+                int ch;
+                uint32_t qg;
+                a.tile.locate(q0, ch, qg);
+                uint32_t off = q0 - (uint32_t)ch * a.tile.plane_local;
+                int r = (int)(qg % (uint32_t)C);
+                const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    row_off[e] = r * L * 16;
+                    int inc = 1;
+                    if (++off == a.tile.plane_local) {
+                        off = 0;
+                        inc += skip_mod;
+                    }
+                    r += inc;
+                    r = r >= C ? r - C : r;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    int ch;
+                    uint32_t qg;
+                    a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
+                    row_off[e] = (int)(qg % (uint32_t)C) * L * 16;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) row_off[e] = 0;
+        }
+
+        // loads are addressed as (wave-uniform exposure base) + (32-bit per-thread byte offset): no 64-bit VALU address math
+        const uint32_t voff = q0 * (uint32_t)sizeof(T), svoff = q0 * 4u;
+
+        // ---- pivot: the running mean of the earlier batches, else the middle exposure's sample ----
+        constexpr int VS = FIRST ? 1 : V;  // state registers exist only when there is state
+        float p[V], WA[VS], varA[VS];
+        double meanA[VS];
+        if constexpr (FIRST) {
+            const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(
+                reinterpret_cast<const char *>(a.stack) + (int64_t)x.probe * a.image_stride * (int64_t)sizeof(T) + voff);
+            const float itp = inv_t[x.probe];
+            static_for<V>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                float lin = code_to_float<T, V, e>(pk) * a.inv_max_code;
+                if constexpr (kLut) {
+                    const uint32_t i0 = code_to_interval<T, V, e>(pk, index_mul);
+                    const float4 g = *reinterpret_cast<const float4 *>(lds + (row_off[e] + (int)(i0 << 4)));
+                    lin = __builtin_fmaf(g.y, code_to_float<T, V, e>(pk) - g.z, g.x);
+                }
+                p[e] = lin * itp;
+            });
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const uint32_t q = a.tile.planar_index(q0 + e);
+                meanA[e] = a.mean_state[q];
+                WA[e] = a.sumw_state[q];
+                if constexpr (kHasStd) varA[e] = a.var_state[q];
+                p[e] = (float)meanA[e];
+            }
+        }
+
+        double mean_o[V];
+        float var_o[V], Wt_o[V];
+        for (int pass = 0;; ++pass) {
+            float W[V], Swy[V], Saa[V], Sac[V], Scc[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) W[e] = Swy[e] = Saa[e] = Sac[e] = Scc[e] = 0.0f;
+
+            // one exposure of this thread's V elements
+            auto reduce = [&](const Packet<T, V> &pk, const Packet<float, V> &sp, int n) {
+                const float it = inv_t[n];
+                float pxv[V], g0[V], gs[V], gx[V], ge[V];
+                static_for<V>([&](auto ec) {  // stage A: issue the V table gathers together
+                    constexpr int e = decltype(ec)::value;
+                    pxv[e] = code_to_float<T, V, e>(pk);
+                    if constexpr (kLut) {
+                        const uint32_t i0 = code_to_interval<T, V, e>(pk, index_mul);
+                        float4 g = *reinterpret_cast<const float4 *>(lds + (row_off[e] + (int)(i0 << 4)));
+                        // without uncertainty the fourth component is unused and LLVM narrows the gather to ds_read_b96,
+                        // which the LDS serves in 8 passes of 8 lanes instead of 4 of 16: keep all four live
+                        if constexpr (!kHasStd) asm volatile("" : "+v"(g.w));
+                        g0[e] = g.x;
+                        gs[e] = g.y;
+                        gx[e] = g.z;
+                        ge[e] = g.w;
+                    }
+                });
+#pragma unroll
+                for (int e = 0; e < V; ++e) {  // stage B: f, weight, running sums
+                    const float px = pxv[e];
+                    float lin, dge;
+                    if constexpr (kLut) {
+                        lin = __builtin_fmaf(gs[e], px - gx[e], g0[e]);
+                        dge = ge[e];
+                    } else {
+                        lin = px * a.inv_max_code;
+                        dge = ce;
+                    }
+                    const float yd = __builtin_fmaf(lin, it, -p[e]);  // y_n - p
+                    if constexpr (kGauss) {
+                        const float dk = __builtin_fmaf(px, dk_mul, dk_add);
+                        const float w = __builtin_amdgcn_exp2f(-dk * dk);
+                        W[e] += w;
+                        Swy[e] = __builtin_fmaf(w, yd, Swy[e]);
+                        if constexpr (kHasStd) {
+                            float wu = w;
+                            if constexpr (STD == CT_STD_MULTIPLIER) wu = w * px;
+                            if constexpr (STD == CT_STD_EXPLICIT) wu = w * sp.v[e];
+                            const float av = dk * wu;
+                            const float cv = __builtin_fmaf(av, yd, (wu * dge) * it);
+                            Saa[e] = __builtin_fmaf(av, av, Saa[e]);
+                            Sac[e] = __builtin_fmaf(av, cv, Sac[e]);
+                            Scc[e] = __builtin_fmaf(cv, cv, Scc[e]);
+                        }
+                    } else {
+                        Swy[e] += yd;
+                        if constexpr (kHasStd) {
+                            float ev = dge * it;
+                            if constexpr (STD == CT_STD_MULTIPLIER) ev *= px;
+                            if constexpr (STD == CT_STD_EXPLICIT) ev *= sp.v[e];
+                            Scc[e] = __builtin_fmaf(ev, ev, Scc[e]);
+                        }
+                    }
+                }
+            };
+
+            // Software pipeline, two exposures ahead, four per trip with rotating registers (A, B, C, D) so that no
+            // packet is copied: a copy would make the wavefront wait for the load it has just issued.
+            auto fetch = [&](int n, Packet<T, V> &pk, Packet<float, V> &sp) {
+                const int nn = n < B ? n : B - 1;  // past the end: re-load the last exposure (cache hit, unused)
+                // The exposure's base address is laundered through an empty asm as a scalar: LLVM then cannot prove the
+                // prefetched packet equal to a fresh load at its use (it would re-load there and drop the prefetch),
+                // and the load keeps the form global_load v, v_offset, s[base] with no vector address arithmetic.
+                uint64_t base = reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)nn * a.image_stride * (int64_t)sizeof(T));
+                asm volatile("" : "+s"(base));
+                pk = load_global<Packet<T, V>>(base, voff);
+                if constexpr (STD == CT_STD_EXPLICIT) {
+                    uint64_t sbase = reinterpret_cast<uint64_t>(a.std_stack) + (uint64_t)((int64_t)nn * a.image_stride * 4);
+                    asm volatile("" : "+s"(sbase));
+                    sp = load_global<Packet<float, V>>(sbase, svoff);
+                }
+            };
+            Packet<T, V> cA, cB, cC, cD;
+            Packet<float, V> sA{}, sB{}, sC{}, sD{};
+            fetch(0, cA, sA);
+            fetch(1, cB, sB);
+            for (int n = 0; n < B; n += 4) {
+                fetch(n + 2, cC, sC);
+                reduce(cA, sA, n);
+                fetch(n + 3, cD, sD);
+                if (n + 1 < B) reduce(cB, sB, n + 1);
+                fetch(n + 4, cA, sA);
+                if (n + 2 < B) reduce(cC, sC, n + 2);
+                fetch(n + 5, cB, sB);
+                if (n + 3 < B) reduce(cD, sD, n + 3);
+            }
+
+            // ---- epilogue: WBOMean update (statistics.py:64-109) and the closed-form variance, division-free ----
+            bool bad[V];
+            float mb_f[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float Wb = kGauss ? W[e] : (float)B;
+                const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
+                float r = __builtin_amdgcn_rcpf(Df);
+                r = r * __builtin_fmaf(-Df, r, 2.0f);
+                const float num = __builtin_fmaf(-p[e], 1e-6f, Swy[e]);  // sum w y - p (W + 1e-6)
+                float q = num * r;
+                q = __builtin_fmaf(__builtin_fmaf(-q, Df, num), r, q);  // m_b - p
+                float Wt = Wb, frac = 1.0f, var = 0.0f, gam = 0.0f;
+                bad[e] = false;
+                if constexpr (FIRST) {
+                    mean_o[e] = (double)p[e] + (double)q;
+                } else {
+                    Wt = WA[e] + Wb;
+                    frac = Wb / Wt;  // float32 division (statistics.py:105)
+                    const double diff = ((double)p[e] - meanA[e]) + (double)q;  // m_b - mean_A
+                    mean_o[e] = __builtin_fma((double)frac, diff, meanA[e]);
+                    gam = (WA[e] / (Wt * Wt)) * (float)diff;
+                    var = varA[e];
+                }
+                Wt_o[e] = Wt;
+                mb_f[e] = p[e] + q;
+                if constexpr (kHasStd) {
+                    const float beta = frac * r;
+                    const float kap = __builtin_fmaf(-beta, q, gam);
+                    const float t1 = beta * beta * Scc[e];
+                    const float t2 = 2.0f * beta * kap * Sac[e];
+                    const float t3 = kap * kap * Saa[e];
+                    const float upd = (t1 + t2) + t3;
+                    if constexpr (kGauss) bad[e] = (t1 + fabsf(t2)) + t3 > kPivotCondLimit * upd;
+                    var += fmaxf(upd, 0.0f) * sv2;
+                }
+                var_o[e] = var;
+            }
+            bool any_bad = false;
+#pragma unroll
+            for (int e = 0; e < V; ++e) any_bad |= bad[e];
+            if (pass == 1 || !__any(any_bad)) break;
+            if (x.retry_count && (threadIdx.x & 63) == 0) atomicAdd(x.retry_count, 1ull);
+            // only the ill-conditioned elements move their pivot: the others recompute exactly what they had, so an
+            // element's result does not depend on which other elements share its wavefront (tiles == whole, bit for bit)
+#pragma unroll
+            for (int e = 0; e < V; ++e) p[e] = bad[e] ? mb_f[e] : p[e];
+        }
+
+        if (keep_state) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const uint32_t q = a.tile.planar_index(q0 + e);
+                a.mean_state[q] = mean_o[e];
+                a.sumw_state[q] = Wt_o[e];
+                if constexpr (kHasStd) a.var_state[q] = var_o[e];
+            }
+        }
+        if (finalize && !planar) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const uint32_t q = a.tile.planar_index(q0 + e);
+                if (a.flags & CT_MERGE_MEAN_OUT_F32)
+                    static_cast<float *>(a.mean_out)[q] = (float)mean_o[e];
+                else
+                    static_cast<double *>(a.mean_out)[q] = mean_o[e];
+                if constexpr (kHasStd) a.std_out[q] = __builtin_amdgcn_sqrtf(var_o[e]);
+            }
+        } else if (finalize) {
+            if (a.flags & CT_MERGE_MEAN_OUT_F32) {
+                Packet<float, V> o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.v[e] = (float)mean_o[e];
+                store_stream(reinterpret_cast<Packet<float, V> *>(static_cast<float *>(a.mean_out) + q0), o);
+            } else {
+                Packet<double, V> o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.v[e] = mean_o[e];
+                store_stream(reinterpret_cast<Packet<double, V> *>(static_cast<double *>(a.mean_out) + q0), o);
+            }
+            if constexpr (kHasStd) {
+                Packet<float, V> o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.v[e] = __builtin_amdgcn_sqrtf(var_o[e]);
+                store_stream(reinterpret_cast<Packet<float, V> *>(a.std_out + q0), o);
+            }
+        }
+    }
+}
+
+// Workgroups of `kernel` that fit one compute unit (registers, LDS, waves), cached per instantiation.
+template <typename KernelT>
+static int pivot_blocks_per_cu(KernelT kernel, size_t lds)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, lds) != hipSuccess || n < 1) n = 1;
+    return n < 8 ? n : 8;
+}
+
+// Persistent grid: as many workgroups as are resident at once (so every workgroup walks the same number of tiles, +-1).
+template <auto kernel>
+static int launch_pivot_grid(const MergeArgs &a, const PivotArgs &x, size_t lds, hipStream_t stream)
+{
+    // residency per kernel (the kernel is a template argument, so these statics are per kernel); it is re-derived when
+    // a later call needs more LDS (a larger LUT)
+    static int per_cu = 0;
+    static size_t per_cu_lds = 0;
+    if (per_cu == 0 || lds > per_cu_lds) {
+        per_cu = pivot_blocks_per_cu(kernel, lds);
+        per_cu_lds = lds;
+    }
+    uint32_t grid = (uint32_t)(compute_units() * per_cu);
+    if (grid > x.n_tiles) grid = x.n_tiles;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a, x);
+    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int V, int INTERP, int WEIGHT, int STD>
+static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
+{
+    if (a.q_count == 0) return CT_OK;
+    x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
+    const size_t lds = (INTERP == CT_INTERP_LINEAR ? (size_t)a.channels * a.n_points * 16 : 0) + sizeof(float) * (size_t)a.batch;
+    if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+    return (a.flags & CT_MERGE_FIRST_BATCH) ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true>>(a, x, lds, stream)
+                                            : launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false>>(a, x, lds, stream);
+}
+
+template <typename T, int V, int INTERP, int WEIGHT>
+static int dispatch_pivot_std(const MergeArgs &a, const PivotArgs &x, int std_mode, hipStream_t s)
+{
+    switch (std_mode) {
+        case CT_STD_NONE: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, x, s);
+        case CT_STD_CONSTANT: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, x, s);
+        case CT_STD_MULTIPLIER: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER>(a, x, s);
+        case CT_STD_EXPLICIT: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT>(a, x, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
+template <typename T, int V>
+static int dispatch_pivot(const MergeArgs &a, const PivotArgs &x, int interp, int weight_mode, int std_mode, hipStream_t s)
+{
+    if (interp == CT_INTERP_LINEAR)
+        return weight_mode == CT_WEIGHT_GAUSS ? dispatch_pivot_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS>(a, x, std_mode, s)
+                                              : dispatch_pivot_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_NONE>(a, x, std_mode, s);
+    return weight_mode == CT_WEIGHT_GAUSS ? dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_GAUSS>(a, x, std_mode, s)
+                                          : dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE>(a, x, std_mode, s);
+}
+
 template <typename T, int V, int INTERP, int WEIGHT, int STD>
 static int launch_one(const MergeArgs &a, hipStream_t stream, bool fold)
 {
@@ -404,6 +880,8 @@ static int dispatch_interp(const MergeArgs &a, int interp, int weight_mode, int 
 // HBM-bound), so 16-byte packets are used.  Rejected on measurement (profiles/r01_harness_*.log): float32 block
 // moments (7 % faster, 1.3e-4 parity error), a two-phase variant caching every sample's (a_n, b_n) in registers to
 // drop the float64 FMAs (exact, but 256 VGPRs and 4-byte loads: 2.4 ms), auto-SLP packed float32 (10 % slower).
+constexpr int kPivotV = 4;  // elements per thread of merge_pivot_kernel (uint16: 8-byte loads, uint8: 4-byte)
+
 template <typename T>
 struct VecWidth {
     // uint8: 8 codes (8-byte loads); uint16: 4 codes (8-byte loads) -- measured 6 % faster than 8 codes per thread
@@ -412,7 +890,8 @@ struct VecWidth {
 };
 
 template <typename T>
-static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s, bool fold)
+static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s, bool fold,
+                       const PivotArgs *pivot = nullptr)
 {
     constexpr int V = VecWidth<T>::value;
     // The packet path needs every packet naturally aligned in every exposure: base pointers and the image
@@ -424,6 +903,29 @@ static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int
                         aligned(a.mean_out, 8 * V) && aligned(a.std_out, 4 * V);
     uint32_t q_vec = vec_ok ? (Q / V) * V : 0;
     int rc = CT_OK;
+    if constexpr (sizeof(T) != 4) {
+        // Eligible integer stacks go through the pivoted float32 kernel whole: packets of kPivotV where the alignment
+        // allows, the ragged rest one element per thread.  Per-element arithmetic is identical in both, so how a stack
+        // is cut into tiles does not change a single bit of the result.
+        if (pivot) {
+            const bool pv_ok = aligned(a.stack, sizeof(T) * kPivotV) && (a.image_stride % kPivotV) == 0 &&
+                               aligned(a.std_stack, 4 * kPivotV) && aligned(a.mean_out, 8 * kPivotV) &&
+                               aligned(a.std_out, 4 * kPivotV);
+            const uint32_t q_pv = pv_ok ? (Q / kPivotV) * kPivotV : 0;
+            if (q_pv) {
+                a.q_begin = 0;
+                a.q_count = q_pv;
+                rc = dispatch_pivot<T, kPivotV>(a, *pivot, interp, weight_mode, std_mode, s);
+                if (rc != CT_OK) return rc;
+            }
+            if (q_pv < Q) {
+                a.q_begin = q_pv;
+                a.q_count = Q - q_pv;
+                rc = dispatch_pivot<T, 1>(a, *pivot, interp, weight_mode, std_mode, s);
+            }
+            return rc;
+        }
+    }
     if (q_vec) {
         a.q_begin = 0;
         a.q_count = q_vec;
@@ -443,6 +945,13 @@ static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int
 // Host check that fma(u, hi, u*lo) == u / max_code for every code (see NormConst in ct_device.hpp).
 extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
 extern "C" int ct_index_constants(float max_code, int n_points, float *hi, float *lo);
+// Host check that (code * index_mul) >> 32 (uint16) / the code itself (uint8) is the reference's LUT interval for every code.
+extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
+
+// Diagnostics (not part of the data path): device counter that merge_pivot_kernel bumps once per wavefront that ran
+// its fallback pass.  NULL (the default) disables counting.  Process-global; set it only around a measurement.
+static unsigned long long *g_merge_retry_counter = nullptr;
+extern "C" void ct_merge_set_retry_counter(unsigned long long *counter_dev) { g_merge_retry_counter = counter_dev; }
 
 extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int32_t batch,
                                   const ct_geometry *geom, const float *std_dev, int32_t std_mode, float std_value,
@@ -506,8 +1015,27 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
             // FOLD needs the LUT index formed from the code to equal the reference's float32 index for every code
             const bool fold = ct_index_constants(max_code, a.n_points, &a.index.hi, &a.index.lo) == CT_OK;
             a.inv_max_code = (float)(1.0 / (double)max_code);
-            return dtype == CT_DTYPE_U8 ? merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold)
-                                        : merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold);
+            // Pivoted float32 kernel: LINEAR / no model on full-range codes whose LUT interval is an exact integer
+            // function of the code (step = max_code / (L-1) integral, verified for every code on the host).
+            PivotArgs px{};
+            const PivotArgs *pivot = nullptr;
+            const float dtype_max = dtype == CT_DTYPE_U8 ? 255.0f : 65535.0f;
+            if (!(flags & CT_MERGE_F64_MOMENTS) && max_code == dtype_max && (interp == CT_INTERP_LINEAR || interp == CT_INTERP_NONE)) {
+                bool ok = true;
+                px.step = 1.0f;
+                if (interp == CT_INTERP_LINEAR) {
+                    ok = ct_pivot_index_constants(max_code, a.n_points, &px.index_mul, &px.step) == CT_OK;
+                    if (ok && dtype == CT_DTYPE_U8) ok = px.step == 1.0f;   // uint8 kernel: the code is the index
+                    if (ok && dtype == CT_DTYPE_U16) ok = px.index_mul != 0;
+                }
+                if (ok) {
+                    px.probe = batch / 2;
+                    px.retry_count = g_merge_retry_counter;
+                    pivot = &px;
+                }
+            }
+            return dtype == CT_DTYPE_U8 ? merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot)
+                                        : merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot);
         }
         case CT_DTYPE_F32: return merge_typed<float>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, false);
     }

@@ -63,6 +63,7 @@ extern "C" {
 #define CT_MERGE_FIRST_BATCH 1u  /* state is not read (WBOMean starts at mean 0, weight 0) */
 #define CT_MERGE_FINALIZE 2u     /* also write mean_out / std_out = sqrt(variance) after this batch */
 #define CT_MERGE_MEAN_OUT_F32 4u /* mean_out is float32 instead of the reference's float64 */
+#define CT_MERGE_F64_MOMENTS 8u  /* diagnostic: keep the float64-moment kernel where the pivoted float32 one would run */
 
 /* Memory layout of one image of a stack.  Outputs and state are always planar (C, H, W) like the reference's tensors.
  * NHWC = the interleaved layout OpenCV decodes to (clair_torch/common/data_io.py:125-154); NHWC_BGR additionally
@@ -115,6 +116,10 @@ int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int
                        const float *std_dev, int32_t std_mode, float std_value, const double *exposure_dev,
                        const ct_icrf *icrf, int32_t weight_mode, double *mean_state_dev, float *sumw_state_dev,
                        float *var_state_dev, void *mean_out_dev, float *std_out_dev, uint32_t flags, void *stream);
+
+/* Diagnostics: device counter bumped once per wavefront of the pivoted merge kernel that had to repeat a batch about the
+ * exact mean (ill-conditioned pivot); NULL disables.  Process-global, not part of the data path. */
+void ct_merge_set_retry_counter(unsigned long long *counter_dev);
 
 /*
  * ct_linearize_std -- body of linearize_dataset_generator for F independent frames

@@ -25,6 +25,7 @@ __global__ void fill_random(uint16_t *p, size_t n, uint32_t seed, int mode, size
         } else {
             int nn = (int)(i / Q);
             float E = (h >> 8) * (1.0f / 16777216.0f) * 2.0f / 0.0146f;
+            if (mode == 2) E = (float)((i % Q) % 4096u) * (1.0f / 4096.0f) * 2.0f / 0.0146f;  // smooth ramp along a row
             float t = 0.001f * exp2f(nn * 0.25f);
             float lin = fminf(E * t, 1.0f);
             p[i] = (uint16_t)rintf(powf(lin, 1.0f / 2.2f) * 65535.0f);
@@ -73,6 +74,33 @@ void launch_v(const MergeArgs &a0, hipStream_t s)
     hipLaunchKernelGGL((merge_kernel<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, true, PF>), dim3(grid), dim3(kBlock), lds, s, a);
 }
 
+static PivotArgs g_px;
+template <int STD, int V = kPivotV>
+void launch_pivot_v(const MergeArgs &a0, hipStream_t s)
+{
+    MergeArgs a = a0;
+    a.q_count = (a.q_count / (kBlock * V)) * (kBlock * V);
+    int rc = launch_pivot<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD>(a, g_px, s);
+    if (rc != CT_OK) { printf("launch_pivot rc %d\n", rc); exit(1); }
+}
+
+// compare two result sets on the device: max element-wise relative error, norm-wise relative error
+__global__ void compare_kernel(const double *m0, const float *s0, const double *m1, const float *s1, size_t n, double *acc)
+{
+    // acc: [0] sum (m1-m0)^2 [1] sum m0^2 [2] sum (s1-s0)^2 [3] sum s0^2 [4] max rel mean (bits) [5] max rel std (bits)
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, mx0 = 0, mx1 = 0;
+    for (; i < n; i += stride) {
+        double dm = m1[i] - m0[i], ds = (double)s1[i] - (double)s0[i];
+        a0 += dm * dm; a1 += m0[i] * m0[i]; a2 += ds * ds; a3 += (double)s0[i] * s0[i];
+        mx0 = fmax(mx0, fabs(dm) / fmax(fabs(m0[i]), 1e-300));
+        mx1 = fmax(mx1, fabs(ds) / fmax(fabs((double)s0[i]), 1e-300));
+    }
+    atomicAdd(acc + 0, a0); atomicAdd(acc + 1, a1); atomicAdd(acc + 2, a2); atomicAdd(acc + 3, a3);
+    atomicMax((unsigned long long *)(acc + 4), (unsigned long long)__double_as_longlong(mx0));
+    atomicMax((unsigned long long *)(acc + 5), (unsigned long long)__double_as_longlong(mx1));
+}
+
 int main(int argc, char **argv)
 {
     int N = argc > 1 ? atoi(argv[1]) : 32, H = argc > 2 ? atoi(argv[2]) : 4096, Wd = argc > 3 ? atoi(argv[3]) : 4096;
@@ -96,19 +124,30 @@ int main(int argc, char **argv)
     a.inv_max_code = (float)(1.0 / 65535.0); a.std_value = 0.05f; a.weight_scale = 30.0f;
     a.flags = CT_MERGE_FIRST_BATCH | CT_MERGE_FINALIZE;
 
+    if (ct_pivot_index_constants(65535.0f, 256, &g_px.index_mul, &g_px.step) != CT_OK) { printf("pivot index refused\n"); return 1; }
+    g_px.probe = N / 2;
+    unsigned long long *retries; CK(hipMalloc(&retries, 8)); CK(hipMemset(retries, 0, 8));
+    g_px.retry_count = retries;
+    double *mean2; float *std2; double *acc;
+    CK(hipMalloc(&mean2, Q * 8)); CK(hipMalloc(&std2, Q * 4)); CK(hipMalloc(&acc, 6 * 8));
     std::vector<Variant> vs = {
+        {"pivot V4 mult", launch_pivot_v<CT_STD_MULTIPLIER>}, {"pivot V4 nostd", launch_pivot_v<CT_STD_NONE>},
+        {"pivot V2 mult", launch_pivot_v<CT_STD_MULTIPLIER, 2>}, {"pivot V8 mult", launch_pivot_v<CT_STD_MULTIPLIER, 8>},
         {"stream V4 (8B/lane)", launch_stream<4>}, {"stream V8 (16B/lane)", launch_stream<8>},
-        {"V8 PF1 mult", launch_v<8, 1, CT_STD_MULTIPLIER>}, {"V8 PF2 mult", launch_v<8, 2, CT_STD_MULTIPLIER>},
-        {"V4 PF1 mult", launch_v<4, 1, CT_STD_MULTIPLIER>}, {"V4 PF2 mult", launch_v<4, 2, CT_STD_MULTIPLIER>},
-        {"V4 PF3 mult", launch_v<4, 3, CT_STD_MULTIPLIER>},
-        {"V8 PF2 nostd", launch_v<8, 2, CT_STD_NONE>}, {"V4 PF2 nostd", launch_v<4, 2, CT_STD_NONE>},
+        {"f64 V4 PF2 mult", launch_v<4, 2, CT_STD_MULTIPLIER>}, {"f64 V4 PF2 nostd", launch_v<4, 2, CT_STD_NONE>},
     };
+    const char *only = argc > 5 ? argv[5] : nullptr;   // run only the variants whose name contains this (for rocprofv3 --pmc)
+    if (only) {
+        std::vector<Variant> keep;
+        for (auto &v : vs) if (v.name.find(only) != std::string::npos) keep.push_back(v);
+        vs = keep;
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double bytes = (double)S * 2 + (double)Q * 12;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = only ? 1 : 0; mode < (only ? 2 : 3); ++mode) {
         hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, stack, S, 12345u, mode, Q);
         CK(hipDeviceSynchronize());
-        printf("== data: %s, N=%d %dx%d, algorithmic bytes %.3f GB ==\n", mode == 0 ? "uniform random codes" : "gamma-2.2 scene", N, H, Wd, bytes / 1e9);
+        printf("== data: %s, N=%d %dx%d, algorithmic bytes %.3f GB ==\n", mode == 0 ? "uniform random codes" : mode == 1 ? "gamma-2.2 scene, independent pixels" : "gamma-2.2 scene, smooth ramp", N, H, Wd, bytes / 1e9);
         std::vector<std::vector<float>> ms(vs.size());
         for (int r = 0; r < rounds + 1; ++r)
             for (size_t v = 0; v < vs.size(); ++v) {
@@ -120,6 +159,19 @@ int main(int argc, char **argv)
                 if (r > 0) ms[v].push_back(t);
             }
         CK(hipGetLastError());
+        {   // parity of the pivoted float32 kernel against the float64-moment kernel on this data
+            MergeArgs b = a; b.mean_out = mean2; b.std_out = std2;
+            launch_v<4, 2, CT_STD_MULTIPLIER>(a, 0);
+            CK(hipMemset(retries, 0, 8));
+            launch_pivot_v<CT_STD_MULTIPLIER>(b, 0);
+            CK(hipMemset(acc, 0, 48));
+            const size_t nq = (Q / (kBlock * kPivotV)) * (kBlock * kPivotV);
+            hipLaunchKernelGGL(compare_kernel, dim3(2048), dim3(256), 0, 0, mean, stdo, mean2, std2, nq, acc);
+            double h[6]; unsigned long long hr;
+            CK(hipMemcpy(h, acc, 48, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hr, retries, 8, hipMemcpyDeviceToHost));
+            printf("pivot vs f64: mean norm %.3g max %.3g | std norm %.3g max %.3g | fallback wavefronts %llu of %zu\n",
+                   sqrt(h[0] / h[1]), h[4], sqrt(h[2] / h[3]), h[5], hr, nq / 256);
+        }
         for (size_t v = 0; v < vs.size(); ++v) {
             std::sort(ms[v].begin(), ms[v].end());
             float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
