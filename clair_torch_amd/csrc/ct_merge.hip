@@ -416,25 +416,32 @@ __device__ __forceinline__ uint32_t code_to_interval(const Packet<T, V> &pk, uin
         return pk.v[E];
 }
 
-// One packet from global memory at (wave-uniform 64-bit base) + (32-bit per-thread byte offset).
+// One packet through a buffer descriptor based at `base` (wave-uniform) + a 32-bit per-thread byte offset:
+// buffer_load_* v, v_offset, s[descriptor], 0 offen.  The descriptor spans 4 GiB from the base, so the offset (an
+// element index inside ONE image times the element size) must stay below that -- the callers check.
 template <typename P>
-__device__ __forceinline__ P load_global(uint64_t base, uint32_t offset)
+__device__ __forceinline__ P load_buffer(uint64_t base, uint32_t offset)
 {
-    const GLOBAL_AS char *ptr = reinterpret_cast<const GLOBAL_AS char *>(base) + offset;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, 0xffffffff, 0x00020000 /* gfx9 raw dword format */);
     P out;
     if constexpr (sizeof(P) == 1) {
-        const uint8_t v = *reinterpret_cast<const GLOBAL_AS uint8_t *>(ptr);
+        const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(rsrc, offset, 0, 0);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else if constexpr (sizeof(P) == 2) {
-        const uint16_t v = *reinterpret_cast<const GLOBAL_AS uint16_t *>(ptr);
+        const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(rsrc, offset, 0, 0);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else if constexpr (sizeof(P) == 4) {
-        const uint32_t v = *reinterpret_cast<const GLOBAL_AS uint32_t *>(ptr);
+        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offset, 0, 0);
+        __builtin_memcpy(&out, &v, sizeof(P));
+    } else if constexpr (sizeof(P) == 8) {
+        typedef uint32_t vec_t __attribute__((ext_vector_type(2)));
+        const vec_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else {
-        static_assert(sizeof(P) % 4 == 0, "wide packets are whole dwords");
-        typedef uint32_t vec_t __attribute__((ext_vector_type(sizeof(P) / 4)));
-        const vec_t v = *reinterpret_cast<const GLOBAL_AS vec_t *>(ptr);
+        static_assert(sizeof(P) == 16, "packets are at most 16 bytes");
+        typedef uint32_t vec_t __attribute__((ext_vector_type(4)));
+        const vec_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offset, 0, 0);
         __builtin_memcpy(&out, &v, sizeof(P));
     }
     return out;
@@ -458,10 +465,17 @@ struct PivotArgs {
     unsigned long long *retry_count;  // diagnostics: wavefronts that ran the fallback pass (may be NULL)
 };
 
-constexpr float kPivotCondLimit = 8.0f;  // sum |terms| / result above which a wavefront repeats the batch about the mean
+#ifndef CT_PIVOT_DEPTH
+#define CT_PIVOT_DEPTH 2
+#endif
+constexpr int kPivotDepth = CT_PIVOT_DEPTH;  // exposures in flight per thread
+constexpr float kPivotCondLimit = 8.0f;
+constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which the table keeps {g[i], S}: error bound 2^-25 * 64 = 2e-6  // sum |terms| / result above which a wavefront repeats the batch about the mean
 
+// The first-batch kernels (no state carried through the loop) fit 64 VGPRs without spilling: ask for 8 wavefronts per
+// SIMD (measured up to 10 % faster than the 6 the default allocation of 76 gives; the state-carrying ones keep 6).
 #ifndef CT_PIVOT_KERNEL_ATTR
-#define CT_PIVOT_KERNEL_ATTR
+#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? 8 : 4, 8)))
 #endif
 template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST>
 __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kernel(const MergeArgs a, const PivotArgs x)
@@ -470,31 +484,52 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     static_assert(sizeof(T) != 4, "raw integer codes only");
     static_assert(INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_NONE, "LOOKUP / CATMULL use merge_kernel");
     constexpr bool kLut = INTERP == CT_INTERP_LINEAR;
-    constexpr bool kDirect = sizeof(T) == 1;  // uint8: L - 1 == max_code, the code is the index
     constexpr bool kHasStd = STD != CT_STD_NONE;
     constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
     const int C = a.channels, L = a.n_points, B = a.batch;
-    const int lut_bytes = kLut ? C * L * 16 : 0;
-    float *inv_t = reinterpret_cast<float *>(lds + lut_bytes);
-    const float top = kLut ? (float)(L - 1) : 1.0f;
+    const int lut_bytes = kLut ? C * L * 8 : 0;
+    float2 *expo = reinterpret_cast<float2 *>(lds + lut_bytes);  // per exposure {1 / t_n, chain factor of the y' term}
     const float kk = sqrtf(a.weight_scale * 1.4426950408889634f);
     const float K = -2.0f * a.weight_scale;
-    const float ce = kGauss ? kk * top / K : top;  // chain factor of the y' term, without 1 / t_n
+    // y' = (df/dcode) max_code / t_n;  the loop forms (w s' df/dcode) * cq_n with cq_n = max_code (kk / K) / t_n
+    const float max_code = kLut ? x.step * (float)(L - 1) : 1.0f;  // (no model: df/dcode * max_code = 1, folded)
+    const float ce = kGauss ? max_code * kk / K : max_code;
 
+    bool rough = false;
     if constexpr (kLut) {
+        // entry i of row r: f(code) = A + S * code on [i * step, (i + 1) * step):  S = (g[i+1] - g[i]) / step (the
+        // reference backward's g1 - g0), A = g[i] - S * i * step formed in float64 and rounded once.  One FMA per
+        // sample, but A carries an absolute rounding error of 2^-25 |A|, and |A| <= |g[i]| + i |g[i+1] - g[i]| exceeds
+        // the LUT values themselves when the curve is steep: a factor 1 + p for g = x^p, unbounded for a LUT with a
+        // jump.  A workgroup that meets |A| > kRoughLimit max(|g[i]|, |g[i+1]|) anywhere therefore stages {g[i], S}
+        // instead and evaluates f = g[i] + S (code - i * step) with the offset formed exactly (two more instructions
+        // per sample); every workgroup sees the same LUT, so all take the same branch.
         const int total = C * L;
-        const float inv_step = 1.0f / x.step;
+        bool viol = false;
         for (int k = threadIdx.x; k < total; k += kBlock) {
             const int r = k / L, i = k - r * L;
             const float *row = a.lut + (size_t)r * L;
-            const float g0 = row[i], dg = row[i + 1 < L ? i + 1 : L - 1] - g0;  // the reference backward's g1 - g0
-            reinterpret_cast<float4 *>(lds)[k] = make_float4(g0, dg * inv_step, (float)i * x.step, dg * ce);
+            const float g0 = row[i], g1 = row[i + 1 < L ? i + 1 : L - 1];
+            const float slope = (g1 - g0) / x.step;
+            const float A = (float)((double)g0 - (double)slope * ((double)i * (double)x.step));
+            viol |= !(fabsf(A) <= kRoughLimit * fmaxf(fmaxf(fabsf(g0), fabsf(g1)), 1e-30f));
+        }
+        rough = __syncthreads_or(viol);
+        for (int k = threadIdx.x; k < total; k += kBlock) {
+            const int r = k / L, i = k - r * L;
+            const float *row = a.lut + (size_t)r * L;
+            const float g0 = row[i], g1 = row[i + 1 < L ? i + 1 : L - 1];
+            const float slope = (g1 - g0) / x.step;
+            const float A = (float)((double)g0 - (double)slope * ((double)i * (double)x.step));
+            reinterpret_cast<float2 *>(lds)[k] = make_float2(rough ? g0 : A, slope);
         }
     }
-    for (int n = threadIdx.x; n < B; n += kBlock) inv_t[n] = (float)(1.0 / a.exposure[n]);
+    for (int n = threadIdx.x; n < B; n += kBlock) {
+        const float it = (float)(1.0 / a.exposure[n]);
+        expo[n] = make_float2(it, ce * it);
+    }
     __syncthreads();  // the only barrier: everything below is per wavefront
 
-    constexpr bool first = FIRST;  // CT_MERGE_FIRST_BATCH: no state is read, and none is carried through the loop
     const bool finalize = a.flags & CT_MERGE_FINALIZE;
     const bool keep_state = a.mean_state != nullptr;
     const bool planar = a.tile.layout == CT_LAYOUT_NCHW;
@@ -522,7 +557,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    row_off[e] = r * L * 16;
+                    row_off[e] = r * L * 8;
                     int inc = 1;
                     if (++off == a.tile.plane_local) {
                         off = 0;
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     int ch;
                     uint32_t qg;
                     a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
-                    row_off[e] = (int)(qg % (uint32_t)C) * L * 16;
+                    row_off[e] = (int)(qg % (uint32_t)C) * L * 8;
                 }
             }
         } else {
@@ -553,16 +588,17 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         float p[V], WA[VS], varA[VS];
         double meanA[VS];
         if constexpr (FIRST) {
-            const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(
-                reinterpret_cast<const char *>(a.stack) + (int64_t)x.probe * a.image_stride * (int64_t)sizeof(T) + voff);
-            const float itp = inv_t[x.probe];
+            const Packet<T, V> pk = load_buffer<Packet<T, V>>(
+                reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)x.probe * a.image_stride * (int64_t)sizeof(T)), voff);
+            const float itp = expo[x.probe].x;
             static_for<V>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 float lin = code_to_float<T, V, e>(pk) * a.inv_max_code;
                 if constexpr (kLut) {
                     const uint32_t i0 = code_to_interval<T, V, e>(pk, index_mul);
-                    const float4 g = *reinterpret_cast<const float4 *>(lds + (row_off[e] + (int)(i0 << 4)));
-                    lin = __builtin_fmaf(g.y, code_to_float<T, V, e>(pk) - g.z, g.x);
+                    const float2 g = *reinterpret_cast<const float2 *>(lds + (row_off[e] + (int)(i0 << 3)));
+                    const float px = code_to_float<T, V, e>(pk);
+                    lin = __builtin_fmaf(g.y, rough ? __builtin_fmaf((float)i0, -x.step, px) : px, g.x);
                 }
                 p[e] = lin * itp;
             });
@@ -584,40 +620,43 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 #pragma unroll
             for (int e = 0; e < V; ++e) W[e] = Swy[e] = Saa[e] = Sac[e] = Scc[e] = 0.0f;
 
+            auto run_batch = [&](auto rough_c) {
+            constexpr bool kRough = decltype(rough_c)::value;  // see the staging: exact but slower interval arithmetic
             // one exposure of this thread's V elements
             auto reduce = [&](const Packet<T, V> &pk, const Packet<float, V> &sp, int n) {
-                const float it = inv_t[n];
-                float pxv[V], g0[V], gs[V], gx[V], ge[V];
-                static_for<V>([&](auto ec) {  // stage A: issue the V table gathers together
+                const float2 ex = expo[n];
+                const float it = ex.x, cqn = ex.y;
+                float pxv[V], ga[V], gs[V];
+                [[maybe_unused]] float pxl[V];
+                [[maybe_unused]] float dkv[V], wv[V];
+                static_for<V>([&](auto ec) {  // stage A: the V table gathers and the V transcendentals, each issued together
                     constexpr int e = decltype(ec)::value;
                     pxv[e] = code_to_float<T, V, e>(pk);
                     if constexpr (kLut) {
                         const uint32_t i0 = code_to_interval<T, V, e>(pk, index_mul);
-                        float4 g = *reinterpret_cast<const float4 *>(lds + (row_off[e] + (int)(i0 << 4)));
-                        // without uncertainty the fourth component is unused and LLVM narrows the gather to ds_read_b96,
-                        // which the LDS serves in 8 passes of 8 lanes instead of 4 of 16: keep all four live
-                        if constexpr (!kHasStd) asm volatile("" : "+v"(g.w));
-                        g0[e] = g.x;
+                        const float2 g = *reinterpret_cast<const float2 *>(lds + (row_off[e] + (int)(i0 << 3)));
+                        ga[e] = g.x;
                         gs[e] = g.y;
-                        gx[e] = g.z;
-                        ge[e] = g.w;
+                        if constexpr (kRough) pxl[e] = __builtin_fmaf((float)i0, -x.step, pxv[e]);  // code - i * step, exact
+                    }
+                    if constexpr (kGauss) {
+                        dkv[e] = __builtin_fmaf(pxv[e], dk_mul, dk_add);
+                        wv[e] = __builtin_amdgcn_exp2f(-dkv[e] * dkv[e]);
                     }
                 });
+                if constexpr (kGauss) {
+                    // pins the four v_exp_f32 ahead of the dependent arithmetic: measured 4 % faster than letting the
+                    // scheduler sink each one next to its first use (profiles/r02_merge_ablation.md)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) asm volatile("" : "+v"(wv[e]));
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) {  // stage B: f, weight, running sums
                     const float px = pxv[e];
-                    float lin, dge;
-                    if constexpr (kLut) {
-                        lin = __builtin_fmaf(gs[e], px - gx[e], g0[e]);
-                        dge = ge[e];
-                    } else {
-                        lin = px * a.inv_max_code;
-                        dge = ce;
-                    }
+                    const float lin = kLut ? __builtin_fmaf(gs[e], kRough ? pxl[e] : px, ga[e]) : px * a.inv_max_code;
                     const float yd = __builtin_fmaf(lin, it, -p[e]);  // y_n - p
                     if constexpr (kGauss) {
-                        const float dk = __builtin_fmaf(px, dk_mul, dk_add);
-                        const float w = __builtin_amdgcn_exp2f(-dk * dk);
+                        const float dk = dkv[e], w = wv[e];
                         W[e] += w;
                         Swy[e] = __builtin_fmaf(w, yd, Swy[e]);
                         if constexpr (kHasStd) {
@@ -625,7 +664,8 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                             if constexpr (STD == CT_STD_MULTIPLIER) wu = w * px;
                             if constexpr (STD == CT_STD_EXPLICIT) wu = w * sp.v[e];
                             const float av = dk * wu;
-                            const float cv = __builtin_fmaf(av, yd, (wu * dge) * it);
+                            const float ev = kLut ? (wu * gs[e]) * cqn : wu * cqn;
+                            const float cv = __builtin_fmaf(av, yd, ev);
                             Saa[e] = __builtin_fmaf(av, av, Saa[e]);
                             Sac[e] = __builtin_fmaf(av, cv, Sac[e]);
                             Scc[e] = __builtin_fmaf(cv, cv, Scc[e]);
@@ -633,7 +673,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     } else {
                         Swy[e] += yd;
                         if constexpr (kHasStd) {
-                            float ev = dge * it;
+                            float ev = kLut ? gs[e] * cqn : cqn;
                             if constexpr (STD == CT_STD_MULTIPLIER) ev *= px;
                             if constexpr (STD == CT_STD_EXPLICIT) ev *= sp.v[e];
                             Scc[e] = __builtin_fmaf(ev, ev, Scc[e]);
@@ -642,36 +682,42 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 }
             };
 
-            // Software pipeline, two exposures ahead, four per trip with rotating registers (A, B, C, D) so that no
-            // packet is copied: a copy would make the wavefront wait for the load it has just issued.
+            // Software pipeline: kDepth exposures in flight per thread, kDepth + 1 per trip through rotating registers
+            // (the slot freed by one step is re-filled by the next), so that no packet is ever copied -- a copy would
+            // make the wavefront wait for the load it has just issued.
             auto fetch = [&](int n, Packet<T, V> &pk, Packet<float, V> &sp) {
                 const int nn = n < B ? n : B - 1;  // past the end: re-load the last exposure (cache hit, unused)
-                // The exposure's base address is laundered through an empty asm as a scalar: LLVM then cannot prove the
-                // prefetched packet equal to a fresh load at its use (it would re-load there and drop the prefetch),
-                // and the load keeps the form global_load v, v_offset, s[base] with no vector address arithmetic.
+                // Buffer loads: (scalar descriptor rebased to the exposure) + (32-bit per-thread byte offset) -- no vector
+                // address arithmetic.  The base is laundered through an empty asm so LLVM cannot prove the prefetched
+                // packet equal to a fresh load at its use (it would re-load there and drop the prefetch).
                 uint64_t base = reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)nn * a.image_stride * (int64_t)sizeof(T));
                 asm volatile("" : "+s"(base));
-                pk = load_global<Packet<T, V>>(base, voff);
+                pk = load_buffer<Packet<T, V>>(base, voff);
                 if constexpr (STD == CT_STD_EXPLICIT) {
                     uint64_t sbase = reinterpret_cast<uint64_t>(a.std_stack) + (uint64_t)((int64_t)nn * a.image_stride * 4);
                     asm volatile("" : "+s"(sbase));
-                    sp = load_global<Packet<float, V>>(sbase, svoff);
+                    sp = load_buffer<Packet<float, V>>(sbase, svoff);
                 }
             };
-            Packet<T, V> cA, cB, cC, cD;
-            Packet<float, V> sA{}, sB{}, sC{}, sD{};
-            fetch(0, cA, sA);
-            fetch(1, cB, sB);
-            for (int n = 0; n < B; n += 4) {
-                fetch(n + 2, cC, sC);
-                reduce(cA, sA, n);
-                fetch(n + 3, cD, sD);
-                if (n + 1 < B) reduce(cB, sB, n + 1);
-                fetch(n + 4, cA, sA);
-                if (n + 2 < B) reduce(cC, sC, n + 2);
-                fetch(n + 5, cB, sB);
-                if (n + 3 < B) reduce(cD, sD, n + 3);
+            constexpr int kRing = kPivotDepth + 1;
+            Packet<T, V> ring[kRing];
+            Packet<float, V> sring[STD == CT_STD_EXPLICIT ? kRing : 1];
+            static_for<kPivotDepth>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                fetch(j, ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0]);
+            });
+            for (int n = 0; n < B; n += kRing) {
+                static_for<kRing>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, slot = (j + kPivotDepth) % kRing;
+                    fetch(n + j + kPivotDepth, ring[slot], sring[STD == CT_STD_EXPLICIT ? slot : 0]);
+                    if (j == 0 || n + j < B) reduce(ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0], n + j);
+                });
             }
+            };
+            if (rough)
+                run_batch(std::true_type{});
+            else
+                run_batch(std::false_type{});
 
             // ---- epilogue: WBOMean update (statistics.py:64-109) and the closed-form variance, division-free ----
             bool bad[V];
@@ -795,7 +841,7 @@ static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
 {
     if (a.q_count == 0) return CT_OK;
     x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
-    const size_t lds = (INTERP == CT_INTERP_LINEAR ? (size_t)a.channels * a.n_points * 16 : 0) + sizeof(float) * (size_t)a.batch;
+    const size_t lds = (INTERP == CT_INTERP_LINEAR ? (size_t)a.channels * a.n_points * 8 : 0) + 2 * sizeof(float) * (size_t)a.batch;
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
     return (a.flags & CT_MERGE_FIRST_BATCH) ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true>>(a, x, lds, stream)
                                             : launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false>>(a, x, lds, stream);

@@ -11,8 +11,9 @@ constexpr int ITERS = 2048;
 #define REP8(S) S S S S S S S S
 #define REP4(S) S S S S
 
-template <int OP> __global__ __launch_bounds__(256) void k(float *out, float seed)
+template <int OP> __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned long long *stamps)
 {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0s = __builtin_amdgcn_s_memrealtime();
     float a = seed + threadIdx.x * 0.001f, b = 1.0000001f, c = 1e-9f, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     unsigned u = __float_as_uint(a) & 0xffffff, m = 16711936u, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     for (int i = 0; i < ITERS; ++i) {
@@ -78,26 +79,40 @@ template <int OP> __global__ __launch_bounds__(256) void k(float *out, float see
         if constexpr (OP == 43) { REP8(asm volatile("v_fmaak_f32 %0, %1, %2, 0x3f800001" : "=v"(r0) : "v"(a), "v"(b));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + w0 + w1 + w2 + w3;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1s = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1s - r0s; }
 }
 
+#include <vector>
+#include <algorithm>
+static unsigned long long *g_stamps;
 template <int OP> void run(const char *name, double per_iter, float *out)
 {
     const int blocks = 256 * 8;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, out, 1.0f, g_stamps);
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, out, 1.0f, g_stamps);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
     const double wave_insts = (double)blocks * 4 * ITERS * per_iter;
     const double per_simd_per_us = wave_insts / 1024.0 / (ms * 1e3);
-    printf("%-44s %.3f ms  => %.2f cycles per wave-instr per SIMD at 2.4 GHz\n", name, ms, 2400.0 / per_simd_per_us);
+    std::vector<unsigned long long> h(2 * blocks);
+    CK(hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> clk, cyc;
+    for (int b = 0; b < blocks; ++b) { clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); cyc.push_back((double)h[2 * b]); }
+    std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+    // a block's 4 waves sit on 4 SIMDs; 8 blocks per CU -> 8 waves per SIMD share the issue port
+    const double cyc_per = cyc[blocks / 2] / ((double)ITERS * per_iter * 8.0);
+    printf("%-44s %.3f ms  => %.2f nominal cycles (2.4 GHz) | in-kernel clock %.2f GHz, %.2f shader cycles per wave-instr per SIMD\n",
+           name, ms, 2400.0 / per_simd_per_us, clk[blocks / 2], cyc_per);
     fflush(stdout);
 }
 
 int main()
 {
     float *out; CK(hipMalloc(&out, 256 * 8 * 256 * 4));
+    CK(hipMalloc(&g_stamps, 256 * 8 * 2 * 8));
     run<0>("v_fma_f32", 8, out);
     run<32>("v_mul_f32", 8, out);
     run<17>("v_add_f32", 8, out);
