@@ -5,7 +5,9 @@ Default workload = BASELINE.json config C2: HDR merge + propagated uncertainty o
 stack (LINEAR ICRF, Gaussian weights, sigma = 0.05 * x derived in-kernel), inputs resident in HBM.
 A "step" is one ct_hdr_merge_batch launch over the whole stack.  With --gpus N every rank merges its own C2-sized row
 band of a (4096*N) x 4096 global image (weak scaling, no data-path collective: pixels are independent); a small RCCL
-all_gather of per-band statistics runs once after the timed region (the C5 "gather of per-tile stats").
+all_gather of per-band statistics runs once after the timed region.  `--scaling strong` is BASELINE config C5 as
+stated: ONE 8192x8192x3 image cut into N row bands of 8192/N rows, with the per-band statistics all_gather inside
+every timed step (fixed total work: the N-GPU value over the 1-GPU value is the speed-up).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -74,10 +76,21 @@ def cpu_baseline_merge(n_exp, stops, seconds=12.0, tile=512):
 
 
 def run_merge(args, rank, world, dev):
+    """C2 per GPU (weak scaling, the default) or C5's own geometry (--scaling strong: one global 8192x8192x3 image cut
+    into `world` row bands of 8192 / world rows, per-band statistics gathered over RCCL inside every timed step)."""
+    from clair_torch_amd import _native as nv
     from clair_torch_amd import ops
     from clair_torch_amd.datasets import synthetic_exposure_stack
-    n_exp, h, w, c = args.exposures, args.height, args.width, 3
-    h_global = h * world
+    n_exp, c = args.exposures, 3
+    strong = args.scaling == "strong"
+    if strong:
+        h_global, w = args.global_size, args.global_size
+        if h_global % world:
+            raise SystemExit(f"--scaling strong: {h_global} rows do not split into {world} equal bands")
+        h = h_global // world
+    else:
+        h, w = args.height, args.width
+        h_global = h * world
     codes, exposures = synthetic_exposure_stack(n_exp, c, h_global, w, bits=16, stops_per_step=0.25, seed=1236,
                                                 device=dev, row_range=(rank * h, (rank + 1) * h))
     lut = make_lut(dev)
@@ -93,9 +106,26 @@ def run_merge(args, rank, world, dev):
         in_bytes += 4
     elif args.std == "none":
         kw.update(std_mode="none")
+    if args.f64_moments:
+        kw.update(force_f64_moments=True)
+
+    def band_stats(mean, std):
+        # per channel: min, max, sum of the mean and of the std.  Two-stage reductions: torch reduces (C, H*W) -> (C)
+        # with three workgroups' worth of parallelism (18 ms per statistic at 8192^2), (C, 4096, -1) -> (C, 4096) -> (C)
+        # takes 0.3 ms (tools/stats_timing.py).
+        def three(t):
+            v = t.reshape(t.shape[0], 4096, -1) if t[0].numel() % 4096 == 0 else t.reshape(t.shape[0], 1, -1)
+            return [v.amin(dim=2).amin(dim=1).double(), v.amax(dim=2).amax(dim=1).double(),
+                    v.sum(dim=2, dtype=torch.float64).sum(dim=1)]
+        if std is None:
+            return torch.stack(three(mean) + [torch.zeros(mean.shape[0], dtype=torch.float64, device=mean.device)] * 3)
+        return torch.stack(three(mean) + three(std))
 
     def step():
-        return ops.hdr_merge_batch(codes, t_dev, **kw)
+        mean, std = ops.hdr_merge_batch(codes, t_dev, **kw)
+        if strong:  # C5: the per-band statistics gather is part of the job
+            return mean, std, gather_stats(band_stats(mean, std), world)
+        return mean, std, None
 
     for _ in range(args.warmup):
         step()
@@ -105,37 +135,47 @@ def run_merge(args, rank, world, dev):
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        mean, std = step()
+        mean, std, gathered = step()
         ev[k][1].record()
     torch.cuda.synchronize()
     barrier(world)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, world, dev)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    # per-band statistics gathered over RCCL (untimed; C5's "gather of per-tile stats")
-    if std is None:
-        std = torch.zeros_like(mean, dtype=torch.float32)
-    stats = torch.stack([mean.amin(dim=(1, 2)), mean.amax(dim=(1, 2)), mean.sum(dim=(1, 2)),
-                         std.double().amin(dim=(1, 2)), std.double().amax(dim=(1, 2)), std.double().sum(dim=(1, 2))])
-    gathered = gather_stats(stats, world)
+    per_launch = sorted(a.elapsed_time(b) for a, b in ev)  # device events on the launch stream (torch's current stream)
+    kernel_ms = sum(per_launch) / args.steps
+    if gathered is None:  # weak mode: per-band statistics gathered once, after the timed region
+        gathered = gather_stats(band_stats(mean, std), world)
     px = h * w
     # stack (+ explicit std) read + float64 mean (+ float32 std) written
     bytes_alg = n_exp * c * px * in_bytes + c * px * (8 + (0 if args.std == "none" else 4))
+    dtype_code = nv.DTYPE_U16 if args.input == "u16" else nv.DTYPE_F32
+    flags = nv.MERGE_FIRST_BATCH | nv.MERGE_FINALIZE | (nv.MERGE_F64_MOMENTS if args.f64_moments else 0)
+    kernel = nv.load().ct_hdr_merge_kernel_name(dtype_code, 65535.0, nv.INTERP_LINEAR, 256, flags).decode()
+    traffic = measured_traffic("merge_c2") if (args.input, args.std, h, w, n_exp) == ("u16", "multiplier", 4096, 4096, 32) else None
+    name = "C5" if strong else "C2"
     out = {
         "metric": "MPix/s HDR-merged (+uncertainty) at N=32 4K RGB", "value": round(world * px * args.steps / elapsed / 1e6, 1),
         "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU, "
+        "config": {"workload": f"{name}: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU, "
                                f"merge{'' if args.std == 'none' else '+uncertainty'} (LINEAR ICRF 3x256, Gaussian weights, "
-                               f"sigma: {args.std}, float64 mean + float32 std out)",
-                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": "ct::merge_kernel (V=4 elements per thread, LINEAR, GAUSS, PF=2)",
+                               f"sigma: {args.std}, float64 mean + float32 std out)"
+                               + (", per-band statistics all_gather (RCCL) inside every step" if strong else ""),
+                   "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": kernel,
                    "finite": bool(torch.isfinite(gathered).all())},
         "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic("merge_c2") if (args.input, args.std) == ("u16", "multiplier") else None,
+                     "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass on this "
+                                       "workload, not measured by this run)" if traffic is not None else None,
                      "bytes_per_launch": bytes_alg,
-                     "kernel_ms": round(kernel_ms, 4)},
+                     "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(per_launch[0], 4),
+                     "kernel_ms_median": round(per_launch[len(per_launch) // 2], 4),
+                     "kernel_ms_max": round(per_launch[-1], 4),
+                     "timing": "hipEvent pairs around each launch on the launch stream"
+                               + (" (includes the statistics reduction and all_gather)" if strong else "")},
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         del codes
@@ -346,6 +386,11 @@ def main():
     ap.add_argument("--input", default="u16", choices=["u16", "f32"], help="merge: stack element type (default = C2)")
     ap.add_argument("--std", default="multiplier", choices=["multiplier", "explicit", "none"],
                     help="merge: uncertainty source (default = C2: sigma = 0.05 x derived in-kernel)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="merge with --gpus N: weak = one C2-sized band per GPU (default); strong = C5, a fixed "
+                         "--global-size^2 image cut into N row bands with the per-band statistics gather in every step")
+    ap.add_argument("--global-size", type=int, default=8192, help="--scaling strong: rows = columns of the global image")
+    ap.add_argument("--f64-moments", action="store_true", help="merge: time the float64-moment kernel (round-1 path)")
     ap.add_argument("--exposures", type=int, default=32)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)

@@ -15,7 +15,7 @@ INTERP_LOOKUP, INTERP_LINEAR, INTERP_CATMULL, INTERP_NONE = 0, 1, 2, 3
 STD_NONE, STD_CONSTANT, STD_MULTIPLIER, STD_EXPLICIT = 0, 1, 2, 3
 WEIGHT_NONE, WEIGHT_GAUSS = 0, 1
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BGR = 0, 1, 2
-MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32 = 1, 2, 4
+MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32, MERGE_F64_MOMENTS = 1, 2, 4, 8
 ERR_NO_GRADIENT_PATH = -4
 
 ABI_VERSION = 2
@@ -75,15 +75,17 @@ def load():
     lib.ct_linearize_fwd.argtypes = [vp, i64, gp, ip, vp, vp]
     lib.ct_linearize_bwd.restype = i32
     lib.ct_linearize_bwd.argtypes = [vp, vp, i64, gp, ip, vp, vp, vp]
-    if True:
-        pp = ctypes.POINTER(PairParams)
-        lib.ct_pair_residual_fwd.restype = i32
-        lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, i32, vp, vp, vp]
-        lib.ct_pair_residual_bwd.restype = i32
-        lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp, vp, i64,
-                                             vp]
-        lib.ct_pair_residual_bwd_workspace.restype = i64
-        lib.ct_pair_residual_bwd_workspace.argtypes = [i32, i32, i32]
+    pp = ctypes.POINTER(PairParams)
+    lib.ct_pair_residual_fwd.restype = i32
+    lib.ct_pair_residual_fwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, vp, vp, i32, pp, i32, vp, vp, vp]
+    lib.ct_pair_residual_bwd.restype = i32
+    lib.ct_pair_residual_bwd.argtypes = [vp, i32, f32, i32, gp, vp, ip, vp, i32, vp, vp, vp, pp, vp, vp, vp, vp, i64, vp]
+    lib.ct_pair_residual_bwd_workspace.restype = i64
+    lib.ct_pair_residual_bwd_workspace.argtypes = [i32, i32, i32]
+    lib.ct_hdr_merge_kernel_name.restype = ctypes.c_char_p
+    lib.ct_hdr_merge_kernel_name.argtypes = [i32, f32, i32, i32, u32]
+    lib.ct_merge_set_retry_counter.restype = None
+    lib.ct_merge_set_retry_counter.argtypes = [vp]
     lib.ct_flatfield_sums.restype = i32
     lib.ct_flatfield_sums.argtypes = [vp, i32, vp, i32, i64, vp, vp]
     lib.ct_flatfield_apply.restype = i32

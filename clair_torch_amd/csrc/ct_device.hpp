@@ -71,7 +71,10 @@ __device__ __forceinline__ void stage_lut(char *lds, const float *__restrict__ l
 // One sample through the staged LUT.
 //   EXACT   : reproduce the reference's float32 operation order bit for bit (linearize path);
 //             otherwise the lerp is a single FMA (merge path, 1e-5 tolerance).
-//   RANGED  : the value is known to lie in [0,1] (integer codes) -> no clamp, derivative mask = 1.
+//   RANGED  : the value comes from an unsigned integer code, so it is >= 0 and only the upper clamp can act: a
+//             code above max_code (12-bit data in a uint16 container normalised by 4095, say) gives x > 1, which the
+//             reference clamps to the top of the LUT with zero gradient (base.py:146,166,190).  One v_min; LINEAR
+//             needs no gradient mask because the last staged interval has zero slope (g[L-1] twice), CATMULL does.
 // Returns f(x); dfdx receives df/dx (0 for LOOKUP).  `row_lds` points at this element's LUT row.
 template <int INTERP, bool EXACT, bool RANGED>
 __device__ __forceinline__ float icrf_sample(float x, const char *row_lds, float top, float &dfdx)
@@ -87,10 +90,13 @@ __device__ __forceinline__ float icrf_sample(float x, const char *row_lds, float
         return reinterpret_cast<const float *>(row_lds)[(int)r];
     } else {
         const float sraw = x * top;  // base.py:166 / 190
-        float s = sraw, pass = 1.0f;
+        float s, pass = 1.0f;
         if constexpr (!RANGED) {
             s = fminf(fmaxf(sraw, 0.0f), top);
             pass = (sraw >= 0.0f && sraw <= top) ? 1.0f : 0.0f;  // clamp backward mask
+        } else {
+            s = fminf(sraw, top);
+            if constexpr (INTERP == CT_INTERP_CATMULL) pass = sraw <= top ? 1.0f : 0.0f;
         }
         const float fl = floorf(s);
         const int i0 = (int)fl;
@@ -99,7 +105,7 @@ __device__ __forceinline__ float icrf_sample(float x, const char *row_lds, float
             const float2 g = reinterpret_cast<const float2 *>(row_lds)[i0];
             const float dg = g.y - g.x;
             dfdx = dg * top;
-            if constexpr (!RANGED) dfdx *= pass;
+            if constexpr (!RANGED) dfdx *= pass;  // (RANGED: dg = 0 on the clamped interval)
             if constexpr (EXACT) {
                 const float a = g.x * (1.0f - fr);  // base.py:182: g0 * (1 - w) + g1 * w, un-fused
                 const float b = g.y * fr;
@@ -127,8 +133,7 @@ __device__ __forceinline__ float icrf_sample(float x, const char *row_lds, float
             // sum (g_k - g_1) d_k: the d_k sum to zero, subtracting g_1 removes the ~100x cancellation
             const float acc = __builtin_fmaf(d0, g.x - g.y, __builtin_fmaf(d2, g.z - g.y, d3 * (g.w - g.y)));
             (void)d1;
-            dfdx = acc * top;
-            if constexpr (!RANGED) dfdx *= pass;
+            dfdx = acc * top * pass;
             return r;
         }
     }

@@ -194,12 +194,17 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
             ga[e] = gb[e] = gc[e] = gd[e] = 0.0f;
             if constexpr (INTERP == CT_INTERP_LOOKUP) {
                 float r = rintf(s);
-                if constexpr (!kRanged) r = fminf(fmaxf(r, 0.0f), top);
+                r = kRanged ? fminf(r, top) : fminf(fmaxf(r, 0.0f), top);  // codes are >= 0: only the upper clamp can act
                 ga[e] = reinterpret_cast<const float *>(lds + row_off[e])[(int)r];
             } else if constexpr (INTERP != CT_INTERP_NONE) {
                 if constexpr (!kRanged) {
                     passv[e] = (s >= 0.0f && s <= top) ? 1.0f : 0.0f;
                     s = fminf(fmaxf(s, 0.0f), top);
+                } else {
+                    // a code above max_code: clamp to the top of the LUT like the reference (base.py:166,190); LINEAR's
+                    // last staged interval has zero slope, CATMULL needs the explicit gradient mask
+                    if constexpr (INTERP == CT_INTERP_CATMULL) passv[e] = s <= top ? 1.0f : 0.0f;
+                    s = fminf(s, top);
                 }
                 const int i0 = (int)s;  // s >= 0: truncation is floor
                 frv[e] = __builtin_amdgcn_fractf(s);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
                 const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
                 const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
                 dfds = __builtin_fmaf(d0, ga[e] - gb[e], __builtin_fmaf(d2, gc[e] - gb[e], d3 * (gd[e] - gb[e])));
-                if constexpr (!kRanged) dfds *= passv[e];
+                dfds *= passv[e];
             }
             const float y = lin * it;
             float sg = 1.0f;
@@ -549,11 +554,13 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         int row_off[V];  // byte offset of each element's LUT row inside the LDS table
         if constexpr (kLut) {
             if (planar) {
-                int ch;
-                uint32_t qg;
-                a.tile.locate(q0, ch, qg);
+                // channel by comparisons, row by a constant-divisor modulo when C == 3: a runtime 32-bit division costs
+                // ~30 instructions, and this runs once per tile per thread
+                int ch = 0;
+                for (int c = 1; c < C; ++c) ch += q0 >= (uint32_t)c * a.tile.plane_local ? 1 : 0;
+                const uint32_t qg = q0 + (uint32_t)ch * a.tile.chan_skip + a.tile.base;
                 uint32_t off = q0 - (uint32_t)ch * a.tile.plane_local;
-                int r = (int)(qg % (uint32_t)C);
+                int r = C == 3 ? (int)(qg % 3u) : (int)(qg % (uint32_t)C);
                 const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
@@ -999,6 +1006,39 @@ extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *
 static unsigned long long *g_merge_retry_counter = nullptr;
 extern "C" void ct_merge_set_retry_counter(unsigned long long *counter_dev) { g_merge_retry_counter = counter_dev; }
 
+// Pivoted float32 kernel: LINEAR / no model on full-range codes whose LUT interval is an exact integer function of the
+// code (step = max_code / (L-1) integral, verified for every code on the host); CT_MERGE_F64_MOMENTS opts out.
+static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_points, uint32_t flags, ct::PivotArgs *px)
+{
+    if (dtype != CT_DTYPE_U8 && dtype != CT_DTYPE_U16) return false;
+    const float dtype_max = dtype == CT_DTYPE_U8 ? 255.0f : 65535.0f;
+    if ((flags & CT_MERGE_F64_MOMENTS) || max_code != dtype_max) return false;
+    if (interp != CT_INTERP_LINEAR && interp != CT_INTERP_NONE) return false;
+    px->step = 1.0f;
+    px->index_mul = 0;
+    if (interp == CT_INTERP_LINEAR) {
+        if (ct_pivot_index_constants(max_code, n_points, &px->index_mul, &px->step) != CT_OK) return false;
+        if (dtype == CT_DTYPE_U8 && px->step != 1.0f) return false;   // uint8 kernel: the code is the index
+        if (dtype == CT_DTYPE_U16 && px->index_mul == 0) return false;
+    }
+    return true;
+}
+
+// Which kernel ct_hdr_merge_batch dispatches for these arguments (bench.py records it next to its numbers).
+extern "C" const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, int32_t interp, int32_t n_points,
+                                                uint32_t flags)
+{
+    ct::PivotArgs px{};
+    if (pivot_eligible(dtype, max_code, interp, interp == CT_INTERP_NONE ? 2 : n_points, flags, &px))
+        return (flags & CT_MERGE_FIRST_BATCH)
+                   ? "ct::merge_pivot_kernel (float32 moments about a per-pixel pivot, persistent workgroups, 4 codes per "
+                     "thread, 8 wavefronts per SIMD, first batch)"
+                   : "ct::merge_pivot_kernel (float32 moments about the running mean, persistent workgroups, 4 codes per "
+                     "thread, streaming state)";
+    return dtype == CT_DTYPE_F32 ? "ct::merge_kernel (float64 moments, float32 pixels, 4 per thread)"
+                                 : "ct::merge_kernel (float64 moments, integer codes)";
+}
+
 extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int32_t batch,
                                   const ct_geometry *geom, const float *std_dev, int32_t std_mode, float std_value,
                                   const double *exposure_dev, const ct_icrf *icrf, int32_t weight_mode,
@@ -1061,24 +1101,12 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
             // FOLD needs the LUT index formed from the code to equal the reference's float32 index for every code
             const bool fold = ct_index_constants(max_code, a.n_points, &a.index.hi, &a.index.lo) == CT_OK;
             a.inv_max_code = (float)(1.0 / (double)max_code);
-            // Pivoted float32 kernel: LINEAR / no model on full-range codes whose LUT interval is an exact integer
-            // function of the code (step = max_code / (L-1) integral, verified for every code on the host).
             PivotArgs px{};
             const PivotArgs *pivot = nullptr;
-            const float dtype_max = dtype == CT_DTYPE_U8 ? 255.0f : 65535.0f;
-            if (!(flags & CT_MERGE_F64_MOMENTS) && max_code == dtype_max && (interp == CT_INTERP_LINEAR || interp == CT_INTERP_NONE)) {
-                bool ok = true;
-                px.step = 1.0f;
-                if (interp == CT_INTERP_LINEAR) {
-                    ok = ct_pivot_index_constants(max_code, a.n_points, &px.index_mul, &px.step) == CT_OK;
-                    if (ok && dtype == CT_DTYPE_U8) ok = px.step == 1.0f;   // uint8 kernel: the code is the index
-                    if (ok && dtype == CT_DTYPE_U16) ok = px.index_mul != 0;
-                }
-                if (ok) {
-                    px.probe = batch / 2;
-                    px.retry_count = g_merge_retry_counter;
-                    pivot = &px;
-                }
+            if (pivot_eligible(dtype, max_code, interp, a.n_points, flags, &px)) {
+                px.probe = batch / 2;
+                px.retry_count = g_merge_retry_counter;
+                pivot = &px;
             }
             return dtype == CT_DTYPE_U8 ? merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot)
                                         : merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot);

@@ -96,13 +96,16 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
                     interp: Optional[str] = "linear", gaussian_weight: bool = True,
                     std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                     max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
-                    tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw"):
+                    tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw",
+                    force_f64_moments: bool = False):
     """One batch of the HDR merge (ct_hdr_merge_batch).  Returns (mean, std|None) when ``finalize`` else None.
 
     stack (B,C,H,W) uint8/uint16 codes (give ``max_code``) or float32 pixels; exposures (B) any float dtype.
     ``state`` carries the streaming state across batches (None = single-batch merge).
     ``layout`` "nhwc" / "nhwc_bgr": the stack is (B,H,W,C) as OpenCV decodes it (an explicit std stack likewise);
     outputs stay planar (C,H,W).
+    ``force_f64_moments`` (diagnostic, CT_MERGE_F64_MOMENTS): keep the float64-moment kernel where the pivoted
+    float32 one would run (tests compare the two).
     """
     _check_stack(stack)
     b = stack.shape[0]
@@ -131,6 +134,8 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
     has_std = std_mode != "none"
     first = state is None or state.batches == 0
     flags = (nv.MERGE_FIRST_BATCH if first else 0) | (nv.MERGE_FINALIZE if finalize else 0)
+    if force_f64_moments:
+        flags |= nv.MERGE_F64_MOMENTS
     if mean_dtype == torch.float32:
         flags |= nv.MERGE_MEAN_OUT_F32
     elif mean_dtype != torch.float64:

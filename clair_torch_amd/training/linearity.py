@@ -24,9 +24,12 @@ from ..models.base import ICRFModelBase
 
 
 def _all_reduce_sum(t: torch.Tensor, group):
-    if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-                             and group is not False):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group if group not in (None, False) else None)
+    """Sum over the ranks of ``group``: None = the default group when one with more than one rank is up, False = this
+    rank only (a caller that shards nothing), a ProcessGroup = that group."""
+    if group is False:
+        return t
+    if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 

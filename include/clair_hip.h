@@ -117,6 +117,9 @@ int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int
                        const ct_icrf *icrf, int32_t weight_mode, double *mean_state_dev, float *sumw_state_dev,
                        float *var_state_dev, void *mean_out_dev, float *std_out_dev, uint32_t flags, void *stream);
 
+/* Diagnostics: a static string naming the kernel ct_hdr_merge_batch dispatches for these arguments. */
+const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, int32_t interp, int32_t n_points, uint32_t flags);
+
 /* Diagnostics: device counter bumped once per wavefront of the pivoted merge kernel that had to repeat a batch about the
  * exact mean (ill-conditioned pivot); NULL disables.  Process-global, not part of the data path. */
 void ct_merge_set_retry_counter(unsigned long long *counter_dev);

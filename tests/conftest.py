@@ -16,3 +16,23 @@ def pytest_configure(config):
 def _build_oracle():
     from oracle import ct_oracle
     ct_oracle.build()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the parity errors every assert_parity call observed (worst per label) next to the other GPU-run artefacts."""
+    try:
+        import json
+        from _util import OBSERVED
+        if not OBSERVED:
+            return
+        worst = {}
+        for o in OBSERVED:
+            w = worst.setdefault((o["test"], o["what"]), dict(o, calls=0))
+            w["calls"] += 1
+            w["norm"], w["elem"] = max(w["norm"], o["norm"]), max(w["elem"], o["elem"])
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_observed.json"), "w") as fh:
+            json.dump(sorted(worst.values(), key=lambda o: -o["elem"] / o["elem_tol"]), fh, indent=1)
+    except Exception as exc:  # never fail a run over the report
+        print(f"parity report not written: {exc}", file=sys.stderr)

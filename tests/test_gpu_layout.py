@@ -1,10 +1,13 @@
 """Raw OpenCV-layout ingest: interleaved (N,H,W,C) stacks, optionally BGR, read directly by the merge
-and linearize kernels.  The per-sample arithmetic and accumulation order are those of the planar path, so results must
-be bit-identical to the planar kernels on the transposed data (which are themselves pinned to the reference)."""
+and linearize kernels.  Comparand: the CPU oracle on cv_to_torch-permuted data (clair_torch/common/general_functions.py:
+315-335: BGR -> RGB channel flip, HWC -> CHW), i.e. what the reference computes after load_image; the bit-equality with
+the planar HIP path (same per-sample arithmetic and accumulation order) is kept as a second assertion."""
 import numpy as np
 import pytest
 import torch
 from torch.utils.data import DataLoader
+
+from _util import assert_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +42,16 @@ def test_merge_interleaved_equals_planar(dev, dtype, shape, mode):
     assert mean_i.shape == (c, h, w) and torch.equal(mean_i, mean_p) and torch.equal(std_i, std_p)
     bgr = planar.flip(1).permute(0, 2, 3, 1).contiguous()          # what cv2.imread would hand over
     mean_b, std_b = ops.hdr_merge_batch(bgr, t, layout="nhwc_bgr", **kw)
+    # oracle on what the reference's cv_to_torch makes of the raw BGR frames: reverse the last axis, HWC -> CHW
+    from oracle import ct_oracle as oc
+    x = oc.normalize_codes(np.ascontiguousarray(bgr.cpu().numpy()[..., ::-1].transpose(0, 3, 1, 2)))
+    mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t.numpy(), lut.cpu().numpy(), mode, True)
+    assert_parity(mean_b.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"nhwc_bgr {mode} mean")
+    assert_parity(std_b.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"nhwc_bgr {mode} std")
+    x_i = oc.normalize_codes(np.ascontiguousarray(nhwc.cpu().numpy().transpose(0, 3, 1, 2)))
+    mean_oi, std_oi = oc.hdr_merge(x_i, x_i * np.float32(0.05), t.numpy(), lut.cpu().numpy(), mode, True)
+    assert_parity(mean_i.cpu().numpy(), mean_oi, rtol=1e-5, norm_tol=1e-6, what=f"nhwc {mode} mean")
+    assert_parity(std_i.cpu().numpy(), std_oi, rtol=1e-5, norm_tol=1e-5, what=f"nhwc {mode} std")
     assert torch.equal(mean_b, mean_p) and torch.equal(std_b, std_p)
     # streaming state (two batches) and row-band tiles with the interleaved layout
     st = ops.MergeState((c, h, w), dev, True)
@@ -62,8 +75,17 @@ def test_linearize_interleaved_equals_planar(dev, dtype):
     lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]).to(dev)
     for mode in ("linear", "catmull"):
         lin_p, sd_p = ops.linearize_frames(planar, lut, mode, std_mode="multiplier", std_value=0.05)
-        lin_i, sd_i = ops.linearize_frames(planar.flip(1).permute(0, 2, 3, 1).contiguous(), lut, mode,
-                                           std_mode="multiplier", std_value=0.05, layout="nhwc_bgr")
+        raw = planar.flip(1).permute(0, 2, 3, 1).contiguous()
+        lin_i, sd_i = ops.linearize_frames(raw, lut, mode, std_mode="multiplier", std_value=0.05, layout="nhwc_bgr")
+        # oracle on cv_to_torch(raw): value bit-exact, LINEAR std bit-exact (as for the planar path)
+        from oracle import ct_oracle as oc
+        x = oc.normalize_codes(np.ascontiguousarray(raw.cpu().numpy()[..., ::-1].transpose(0, 3, 1, 2)))
+        lin_o, sd_o = oc.linearize_std(x, x * np.float32(0.05), lut.cpu().numpy(), mode)
+        assert np.array_equal(lin_i.cpu().numpy(), lin_o)
+        if mode == "linear":
+            assert np.array_equal(sd_i.cpu().numpy(), sd_o)
+        else:
+            assert_parity(sd_i.cpu().numpy(), sd_o, rtol=1e-5, norm_tol=1e-6, what="nhwc_bgr catmull linearize std")
         assert lin_i.shape == lin_p.shape and torch.equal(lin_i, lin_p) and torch.equal(sd_i, sd_p)
 
 

@@ -141,3 +141,31 @@ def test_linearize_streamed_frames_vs_oracle(dev):
         x = oc.normalize_codes(codes)
         lin_o, sd_o = oc.linearize_std(x, x * np.float32(0.05), lut, "linear")
         assert np.array_equal(lin.cpu().numpy(), lin_o) and np.array_equal(sd.cpu().numpy(), sd_o)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_linearize_codes_above_max_code(dev, mode):
+    """uint16 codes above max_code = 4095 (x > 1): value clamps to the top of the LUT, the derivative (and with it the
+    std) is zero there, exactly as the reference's clamp in the model (base.py:146,166,190) -- against the oracle."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(40)
+    codes = rng.integers(0, 4096, size=(2, 3, 9, 13)).astype(np.uint16)
+    codes.reshape(-1)[::5] = rng.integers(4096, 9000, size=codes.reshape(-1)[::5].shape).astype(np.uint16)
+    codes.reshape(-1)[:3] = [4095, 4096, 65535]
+    x = (codes.astype(np.float32) / np.float32(4095.0)).astype(np.float32)
+    lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
+    if mode == "lookup":  # no gradient path: the reference raises with uncertainties (linearization.py:100), value only
+        lin_o, _ = oc.linearize_std(x, None, lut, mode)
+        lin, _ = ops.linearize_frames(torch.from_numpy(codes).to(dev), torch.from_numpy(lut).to(dev), mode,
+                                      want_std=False, max_code=4095.0)
+        assert np.array_equal(lin.cpu().numpy(), lin_o)
+        return
+    lin_o, sd_o = oc.linearize_std(x, x * np.float32(0.05), lut, mode)
+    lin, sd = ops.linearize_frames(torch.from_numpy(codes).to(dev), torch.from_numpy(lut).to(dev), mode,
+                                   std_mode="multiplier", std_value=0.05, max_code=4095.0)
+    assert np.array_equal(lin.cpu().numpy(), lin_o)
+    if mode == "catmull":
+        assert_parity(sd.cpu().numpy(), sd_o, rtol=1e-5, norm_tol=1e-6, what="max_code 4095 catmull linearize std")
+    else:
+        assert np.array_equal(sd.cpu().numpy(), sd_o)

@@ -297,3 +297,54 @@ def test_train_icrf_argument_errors(dev):
         train_icrf(loader, 4, "cuda", model, optimizers=opts, schedulers=[None])
     with pytest.raises(RuntimeError, match="MI355X"):
         train_icrf(loader, 4, "cpu", model)
+
+
+def test_config_c3_full_shape(dev):
+    """BASELINE config C3 at its real shape: 64 exposures x 2048 x 2048 x 3 uint16, threshold 0.25 -> 888 pairs.
+    Exercises what the small fixtures cannot: the multi-round persistent grid, the float64 accumulation across 4 M
+    pixels per channel, the channel skip of the workgroup order.
+    (1) the five sums and the LUT gradient of two ragged row bands add up to the whole image's;
+    (2) a full-width 8-row band cut out of the real stack (global geometry) equals the eager float64-residual oracle:
+        spatial means, per-channel linearity loss, LUT gradient.  The band starts at a row that is a multiple of 3 and
+        has 8 = 2048 (mod 3) rows, so the reference's LUT-row quirk (flat index % C) selects the same rows for the band
+        alone (what the eager oracle sees) as for the band inside the full image (what the kernel is told)."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    from clair_torch_amd.training import linearity_loss
+    from oracle import ct_oracle as oc
+    from oracle import eager_torch as oe
+    n, c, h, w = 64, 3, 2048, 2048
+    codes, exposures = synthetic_exposure_stack(n, c, h, w, bits=16, stops_per_step=0.125, seed=1237, device=dev)
+    t = torch.tensor(exposures, dtype=torch.float64)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    assert i.numel() == 888
+    pairs = ops.PairList(i, j, r, n, dev)
+    lut0 = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.3, 2.5, 2.7)])
+    kw = dict(lut=lut0.to(dev), interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False)
+    whole = ops.pair_residual_sums(codes, pairs, level=1, **kw)
+    assert torch.isfinite(whole).all() and float(whole[..., 4].min()) > 0
+    gen = torch.Generator().manual_seed(3)
+    coef = (torch.rand((pairs.n_pairs, c), generator=gen, dtype=torch.float64) * 1e-6).to(dev)
+    g_whole = ops.pair_residual_lut_grad(codes, pairs, coef, **kw)
+    bands = ((0, 701), (701, h))
+    parts = [ops.pair_residual_sums(codes[:, :, r0:r1].contiguous(), pairs, level=1,
+                                    tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw) for r0, r1 in bands]
+    assert_parity((parts[0] + parts[1]).cpu().numpy(), whole.cpu().numpy(), rtol=1e-9, norm_tol=1e-12, what="C3 sums: bands = whole")
+    g_parts = [ops.pair_residual_lut_grad(codes[:, :, r0:r1].contiguous(), pairs, coef,
+                                          tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw) for r0, r1 in bands]
+    assert_parity((g_parts[0] + g_parts[1]).cpu().numpy(), g_whole.cpu().numpy(), rtol=1e-9, norm_tol=1e-12,
+                  what="C3 LUT gradient: bands = whole")
+    r0, rows = 1023, 8
+    band = codes[:, :, r0:r0 + rows].contiguous()
+    x = torch.from_numpy(oc.normalize_codes(band.cpu().numpy()))
+    lo = lut0.clone().requires_grad_(True)
+    _, lin_o, sp_o = oe.training_loss(x, None, t, lo, "linear", 0.25, 1 / 255, 254 / 255, True, False)
+    grad_o = torch.autograd.grad(lin_o.sum(), lo)[0]
+    lut = lut0.to(dev).requires_grad_(True)
+    lin, sp = linearity_loss(lut, band, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
+                             use_unc_weight=False, tile=ops.TileGeometry(h_global=h, row_offset=r0), group=False)
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="C3 band spatial means")
+    assert_parity(lin.detach().cpu().numpy(), lin_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="C3 band linearity loss")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="C3 band LUT gradient")

@@ -60,3 +60,26 @@ def test_video_stats_large_vs_eager_oracle(dev):
     std = torch.sqrt(m2 / (k - 1)) / k ** 0.5
     assert_parity(mean.cpu().numpy(), mean_o.numpy(), rtol=1e-6, norm_tol=1e-7, what="mean")
     assert_parity(std.cpu().numpy(), std_o.numpy(), rtol=1e-4, norm_tol=1e-6, what="std")
+
+
+@pytest.mark.parametrize("mode", ["linear", "catmull"])
+def test_video_stats_codes_above_max_code(dev, mode):
+    """uint16 codes above max_code = 4095: the in-kernel linearization clamps like the reference's model."""
+    from clair_torch_amd import ops
+    from oracle import eager_torch as oe
+    rng = np.random.default_rng(41)
+    codes = rng.integers(0, 4096, size=(6, 3, 10, 14)).astype(np.uint16)
+    codes.reshape(-1)[::4] = rng.integers(4096, 7000, size=codes.reshape(-1)[::4].shape).astype(np.uint16)
+    lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)])
+    x = torch.from_numpy((codes.astype(np.float32) / np.float32(4095.0)).astype(np.float32))
+    mean_o, std_o = oe.video_mean_std(x, lut, mode, [4, 2])
+    mean = torch.empty((3, 10, 14), dtype=torch.float32, device=dev)
+    m2 = torch.empty_like(mean)
+    k = 0
+    for b in (4, 2):
+        ops.video_stats_batch(torch.from_numpy(codes[k:k + b]).to(dev), mean, m2, k, lut=lut.to(dev), interp=mode,
+                              max_code=4095.0)
+        k += b
+    std = torch.sqrt(m2 / (k - 1)) / k ** 0.5
+    assert_parity(mean.cpu().numpy(), mean_o.numpy(), rtol=1e-6, norm_tol=1e-7, what="max_code 4095 video mean")
+    assert_parity(std.cpu().numpy(), std_o.numpy(), rtol=1e-4, norm_tol=1e-6, what="max_code 4095 video std")
