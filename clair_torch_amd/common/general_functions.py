@@ -1,8 +1,13 @@
 """Small host-side functions on the boundary of the hot path (clair_torch/common/general_functions.py).
 
 These are O(N^2) / O(C*L) bookkeeping on tiny tensors (pair selection) or API-compatible utilities; the per-pixel
-work they feed is done by the HIP kernels.
+work they feed is done by the HIP kernels.  weighted_mean_and_std, flat_field_mean and flatfield_correction are the
+reference's public tensor helpers of the same names: plain torch expressions on whatever device their arguments live
+on, kept so that code written against the reference's helpers keeps working.  The drop-in entry points do not call
+them -- their arithmetic is fused into ct_pair_residual_fwd (the weighted spatial statistics) and ct_flatfield_sums /
+ct_flatfield_apply (the flat-field epilogue).
 """
+import math
 from typing import Optional
 
 import torch
@@ -36,3 +41,58 @@ def get_pairwise_valid_pixel_mask(image_value_stack, i_idx, j_idx, image_std_sta
         si, sj = image_std_stack[i_idx], image_std_stack[j_idx]
         mask = mask & (si >= std_lower) & (si <= std_upper) & (sj >= std_lower) & (sj <= std_upper)
     return mask
+
+
+def weighted_mean_and_std(values: torch.Tensor, weights: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                          dim=None, keepdim=False, eps=1e-8, compute_std: Optional[bool] = True):
+    """Weighted mean and standard deviation over ``dim`` with an optional boolean mask (reference
+    general_functions.py:118-178).  A mask multiplies values AND weights (so masked values count as zeros with zero
+    weight); without weights the mask is the weight.  The total weight is clamped to ``eps``; where it is exactly zero
+    mean and std are zero.  Returns (mean, std | None)."""
+    std = None
+    if mask is not None:
+        m = mask.to(dtype=values.dtype)
+        values = values * m
+        weights = m if weights is None else weights * m
+    if weights is None:
+        mean = values.mean(dim=dim, keepdim=True)
+        if compute_std:
+            std = torch.sqrt(((values - mean) ** 2).mean(dim=dim, keepdim=True))
+    else:
+        total = weights.sum(dim=dim, keepdim=True).clamp(min=eps)
+        empty = total == 0
+        mean = (values * weights).sum(dim=dim, keepdim=True) / total
+        if compute_std:
+            std = torch.sqrt((((values - mean) ** 2) * weights).sum(dim=dim, keepdim=True) / total)
+            std = torch.where(empty, torch.zeros_like(std), std)
+        mean = torch.where(empty, torch.zeros_like(mean), mean)
+    if not keepdim:
+        mean = mean.squeeze(dim) if dim is not None else mean.squeeze()
+        if compute_std:
+            std = std.squeeze(dim) if dim is not None else std.squeeze()
+    return mean, std
+
+
+def flat_field_mean(flat_field: torch.Tensor, mid_area_side_fraction: float) -> torch.Tensor:
+    """Mean over a centred ROI covering ``mid_area_side_fraction`` of each spatial side, per image and channel:
+    (N, C, H, W) -> (N, C, 1, 1) (reference general_functions.py:182-210; both call sites pass 1.0 = whole image)."""
+    if not 0.0 <= mid_area_side_fraction <= 1.0:
+        raise ValueError("mid_area_side_fraction should be between 0.0 and 1.0")
+    _, _, h, w = flat_field.shape
+    dx, dy = math.floor(w * mid_area_side_fraction), math.floor(h * mid_area_side_fraction)
+    first = (math.floor(1 / mid_area_side_fraction) - 1) / 2   # ROI position in units of its own size
+    x0, x1 = math.floor(first * dx), math.floor((first + 1) * dx)
+    y0, y1 = math.floor(first * dy), math.floor((first + 1) * dy)
+    return flat_field[:, :, y0:y1, x0:x1].mean(dim=(-1, -2), keepdim=True)
+
+
+def flatfield_correction(images: torch.Tensor, flatfield: torch.Tensor, flatfield_mean_val: torch.Tensor,
+                         epsilon: float = 1e-6) -> torch.Tensor:
+    """images / (flatfield + epsilon) * flatfield_mean_val with broadcasting (reference general_functions.py:214-238);
+    raises ValueError when the shapes do not broadcast."""
+    for other, name in ((flatfield, "flatfield"), (flatfield_mean_val, "flatfield_mean_val")):
+        try:
+            torch.broadcast_shapes(images.shape, other.shape)
+        except RuntimeError as exc:
+            raise ValueError(f"{name} shape {tuple(other.shape)} is not broadcastable to {tuple(images.shape)}") from exc
+    return (images / (flatfield + epsilon)) * flatfield_mean_val

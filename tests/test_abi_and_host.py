@@ -3,6 +3,7 @@ returns before any launch, the host-side code-normalisation proofs, and the host
 (collation, datasets, transform fusion, pair lists, loud failure without a GPU)."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -231,7 +232,11 @@ def test_reference_import_paths_resolve():
     from clair_torch.models.icrf_model import ICRFModelDirect
     from clair_torch.training.icrf_training import train_icrf
     from clair_torch.training.losses import gaussian_value_weights
+    from clair_torch.training import pixelwise_linearity_loss, compute_spatial_linearity_loss  # training/__init__.py:6
+    from clair_torch.common.general_functions import weighted_mean_and_std, flat_field_mean, flatfield_correction
     from clair_torch.datasets.collate import custom_collate
+    assert all(callable(f) for f in (pixelwise_linearity_loss, compute_spatial_linearity_loss, weighted_mean_and_std,
+                                     flat_field_mean, flatfield_correction))
     from clair_torch.common.enums import InterpMode
     assert all(callable(f) for f in (compute_hdr_image, linearize_dataset_generator, measure_linearity, train_icrf,
                                      gaussian_value_weights, custom_collate))
@@ -370,3 +375,97 @@ def test_pair_backward_workspace_contract(lib):
     assert call(ctypes.c_void_p(0x2000), need - 1) == -1    # too small
     assert call(ctypes.c_void_p(0x2004), need) == -1        # not 32-byte aligned
     assert call(ctypes.c_void_p(0x2000), -5) == -1
+
+
+def test_public_tensor_helpers_match_reference_vectors():
+    """The reference's public helper names that the fused kernels replace on the hot path, kept as plain torch fronts:
+    weighted_mean_and_std / flat_field_mean / flatfield_correction against vectors recorded from the reference
+    (helpers.npz), and pixelwise_linearity_loss -> compute_spatial_linearity_loss chained exactly as train_icrf chains
+    them (icrf_training.py:105-133) against the recorded (P, C) spatial statistics of every loss variant (training.npz)."""
+    from _util import assert_parity, golden
+    from clair_torch_amd.common.general_functions import (flat_field_mean, flatfield_correction,
+                                                          get_pairwise_valid_pixel_mask, get_valid_exposure_pairs,
+                                                          weighted_mean_and_std)
+    from clair_torch_amd.training import (combined_gaussian_pair_weights, compute_spatial_linearity_loss,
+                                          pixelwise_linearity_loss)
+    from oracle import ct_oracle as oc
+    gh = golden("helpers")
+    m, sd = weighted_mean_and_std(torch.from_numpy(gh["wms_v"]), weights=torch.from_numpy(gh["wms_w"]),
+                                  mask=torch.from_numpy(gh["wms_mask"]), dim=(2, 3))
+    assert np.allclose(m.numpy(), gh["wms_mean"], rtol=1e-14, atol=0) and np.allclose(sd.numpy(), gh["wms_std"], rtol=1e-13, atol=0)
+    assert float(m[0, 0]) == 0.0 and float(sd[0, 0]) == 0.0                      # fully masked -> zeros
+    v = torch.arange(24, dtype=torch.float64).view(2, 3, 4)
+    m0, s0 = weighted_mean_and_std(v, dim=2)                                        # reference test_general_functions.py:109-174
+    assert torch.allclose(m0, v.mean(dim=2)) and torch.allclose(s0, v.std(dim=2, unbiased=False))
+    ff = torch.from_numpy(gh["ff_flat"])
+    assert np.array_equal(flat_field_mean(ff, 1.0).numpy(), gh["ff_mean"])
+    assert np.array_equal(flat_field_mean(ff, 0.5).numpy(), gh["ff_mean_half"])
+    with pytest.raises(ValueError):
+        flat_field_mean(ff, 1.5)
+    corrected = flatfield_correction(torch.from_numpy(gh["ff_img"]), ff, torch.from_numpy(gh["ff_mean"]))
+    assert np.array_equal(corrected.numpy(), gh["ff_corrected"])
+    with pytest.raises(ValueError):
+        flatfield_correction(torch.zeros(2, 3, 4, 4), torch.zeros(2, 3, 5, 4), torch.zeros(1, 3, 1, 1))
+
+    g = golden("training")
+    x = torch.from_numpy(oc.normalize_codes(g["train_codes"]))
+    t = torch.from_numpy(g["train_exposures"])
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    mask = get_pairwise_valid_pixel_mask(x, i, j, None, 1 / 255, 254 / 255)
+    assert np.array_equal(mask.sum(dim=(2, 3)).numpy(), g["train_none_mask_popcount"])
+    gw = combined_gaussian_pair_weights(x, i, j)
+    lin, dlin = oc.icrf_forward(x.numpy(), g["train_lut0"], "linear", want_derivative=True)
+    lin = torch.from_numpy(lin)
+    lin_std = (torch.from_numpy(dlin) * (x * 0.05)).abs()                          # icrf_training.py:117-124 with sigma = 0.05 x
+    for sname, stds in (("none", None), ("multiplier", lin_std)):
+        for rel in (True, False):
+            for unc in (True, False):
+                loss, err = pixelwise_linearity_loss(lin, i, j, r, stds, rel)
+                assert loss.dtype == torch.float64 and (err is None) == (stds is None)
+                sp, sp_std, sp_err = compute_spatial_linearity_loss(loss, err, gw, mask, unc)
+                key = f"train_{sname}_linear_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
+                assert_parity(sp.numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " spatial (helpers)")
+                assert_parity(sp_std.numpy(), g[key + "_spatial_std"], rtol=2e-5, norm_tol=5e-6, what=key + " std (helpers)")
+                if stds is not None:
+                    assert_parity(sp_err.numpy(), g[key + "_spatial_err"], rtol=1e-5, norm_tol=2e-6, what=key + " err (helpers)")
+
+
+def test_alias_package_overlays_a_reference_install(tmp_path, monkeypatch):
+    """clair_torch/__init__.py: modules this build does not provide (file settings, parameters, metadata ...) resolve to
+    a reference install when one is importable, attributes missing from a provided module (data_io.load_image) are
+    taken from the reference's module of the same name, and the reference's own `import clair_torch.<hot path>` lands
+    on the MI355X implementation.  The reference install is faked in tmp_path: nothing here reads /root/reference."""
+    import importlib
+    ref = tmp_path / "site" / "clair_torch"
+    (ref / "common").mkdir(parents=True)
+    (ref / "metadata").mkdir()
+    (ref / "__init__.py").write_text("")
+    (ref / "common" / "__init__.py").write_text("raise RuntimeError('the reference common/__init__ must not run: it is aliased')")
+    (ref / "common" / "parameters.py").write_text(
+        "from clair_torch.common.enums import InterpMode\nfrom clair_torch.models.icrf_model import ICRFModelDirect\n"
+        "class Parameters:\n    mode = InterpMode.LINEAR\n    model = ICRFModelDirect\n")
+    (ref / "common" / "data_io.py").write_text("def load_image(path):\n    return ('reference load_image', path)\n")
+    (ref / "metadata" / "__init__.py").write_text("from clair_torch.metadata.imaging import parse\n")
+    (ref / "metadata" / "imaging.py").write_text("def parse(name):\n    return name.split()\n")
+    import clair_torch
+    for name in [n for n in sys.modules if n.startswith(("clair_torch.metadata", "clair_torch.common.parameters",
+                                                          "_clair_torch_reference"))]:
+        del sys.modules[name]
+    # without a reference install: a clear failure
+    with pytest.raises(ImportError):
+        importlib.import_module("clair_torch.common.parameters")
+    from clair_torch.common import data_io
+    with pytest.raises(AttributeError, match="no reference install"):
+        data_io.load_image
+    monkeypatch.setenv("CLAIR_TORCH_REFERENCE", str(ref))
+    importlib.invalidate_caches()
+    params = importlib.import_module("clair_torch.common.parameters")
+    from clair_torch_amd.common.enums import InterpMode
+    from clair_torch_amd.models import ICRFModelDirect
+    assert params.Parameters.mode is InterpMode.LINEAR and params.Parameters.model is ICRFModelDirect
+    assert importlib.import_module("clair_torch.metadata").parse("10ms 50x") == ["10ms", "50x"]
+    assert data_io.load_image("x.tif") == ("reference load_image", "x.tif")
+    assert callable(data_io.load_icrf_txt) and data_io.load_icrf_txt.__module__.startswith("clair_torch_amd")
+    for name in [n for n in sys.modules if n.startswith(("clair_torch.metadata", "clair_torch.common.parameters",
+                                                          "_clair_torch_reference"))]:
+        del sys.modules[name]

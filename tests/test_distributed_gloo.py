@@ -121,3 +121,145 @@ def _worker(rank, world, port, out_dir):
 def test_sharded_linearity_statistics_two_ranks(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+# ---- compute_hdr_image sharded in row bands, flat-field sums all-reduced (BASELINE config C5's host logic) ------------
+class _OracleBackedLibrary:
+    """Stand-in for libclair_hip.so AT THE C ABI for the three entry points compute_hdr_image reaches: the arguments are
+    the real ones (raw addresses of -- here host -- memory, the ct_geometry / ct_icrf structs, flags), the arithmetic
+    is the CPU oracle's.  Everything above the ABI (clair_torch_amd.ops pointer plumbing, the batch loop, the streaming
+    state, the flat-field epilogue with its all-reduce) is the product's own code."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+
+    def _arr(self, ptr, shape, dtype):
+        ptr = getattr(ptr, "value", ptr)
+        if not ptr:
+            return None
+        n = int(np.prod(shape))
+        ctype = {np.float32: self.ct.c_float, np.float64: self.ct.c_double}[dtype]
+        return np.ctypeslib.as_array((ctype * n).from_address(ptr)).reshape(shape)
+
+    def ct_hdr_merge_batch(self, stack, dtype, max_code, batch, geom, std, std_mode, std_value, exposure, icrf, weight_mode,
+                           mean_state, sumw_state, var_state, mean_out, std_out, flags, stream):
+        from clair_torch_amd import _native as nv
+        from oracle import ct_oracle as oc
+        g, ic = geom._obj, icrf._obj
+        assert dtype == nv.DTYPE_F32 and g.layout == nv.LAYOUT_NCHW
+        c, h, w = g.channels, g.h_tile, g.width
+        assert g.image_stride == c * h * w
+        x = self._arr(stack, (batch, c, h, w), np.float32)
+        t = self._arr(exposure, (batch,), np.float64)
+        lut = self._arr(ic.lut_dev, (c, ic.n_points), np.float32)
+        sd = {nv.STD_NONE: None, nv.STD_EXPLICIT: self._arr(std, (batch, c, h, w), np.float32),
+              nv.STD_MULTIPLIER: x * np.float32(std_value), nv.STD_CONSTANT: np.full_like(x, np.float32(std_value))}[std_mode]
+        st = oc.MergeState(c, h, w)
+        first = bool(flags & nv.MERGE_FIRST_BATCH)
+        if getattr(mean_state, "value", mean_state):
+            st.mean = self._arr(mean_state, (c, h, w), np.float64)
+            st.sumw = self._arr(sumw_state, (c, h, w), np.float32)
+            st.var = self._arr(var_state, (c, h, w), np.float32) if getattr(var_state, "value", var_state) else st.var
+            if first:
+                st.mean[...] = 0
+                st.sumw[...] = 0
+                st.var[...] = 0
+        st.first = first
+        mode = {nv.INTERP_LOOKUP: "lookup", nv.INTERP_LINEAR: "linear", nv.INTERP_CATMULL: "catmull"}[ic.interp]
+        oc.hdr_merge_batch(st, x, sd, t, lut, mode, weight_mode == nv.WEIGHT_GAUSS, tile=(g.h_global, g.row_offset))
+        if flags & nv.MERGE_FINALIZE:
+            self._arr(mean_out, (c, h, w), np.float64)[...] = st.mean
+            if sd is not None:
+                self._arr(std_out, (c, h, w), np.float32)[...] = np.sqrt(st.var)
+        return 0
+
+    def ct_flatfield_sums(self, value, is_f64, flat, c, plane, sums, stream):
+        f = self._arr(flat, (c, plane), np.float32)
+        s = self._arr(sums, (c, 2), np.float64)
+        s[:, 0] += f.astype(np.float64).sum(axis=1)
+        v = self._arr(value, (c, plane), np.float64 if is_f64 else np.float32)
+        if v is not None:
+            s[:, 1] += (v.astype(np.float64) / (f + np.float32(1e-6)).astype(np.float64)).sum(axis=1)
+        return 0
+
+    def ct_flatfield_apply(self, value, is_f64, frames, var_or_std, input_is_variance, flat, flat_std, flat_mean, through,
+                           c, plane, stream):
+        assert is_f64 and frames == 1 and input_is_variance
+        v = self._arr(value, (c, plane), np.float64)
+        var = self._arr(var_or_std, (c, plane), np.float32)
+        f, fs = self._arr(flat, (c, plane), np.float32), self._arr(flat_std, (c, plane), np.float32)
+        m, th = self._arr(flat_mean, (c,), np.float32), self._arr(through, (c,), np.float64)
+        den = (f + np.float32(1e-6)).astype(np.float64)
+        grad = (-v * m.astype(np.float64)[:, None] / (den * den) + th[:, None]).astype(np.float32)
+        v[...] = v / den * m.astype(np.float64)[:, None]
+        var[...] = np.sqrt(var + (grad * fs) ** 2)
+        return 0
+
+    def ct_error_string(self, code):
+        return b"stand-in"
+
+
+def _hdr_scene():
+    gen = torch.Generator().manual_seed(77)
+    n, c, h, w = 6, 3, 11, 7          # (rows * W) % C != 0 for both bands: the LUT-row quirk needs the global geometry
+    t = torch.tensor([0.002 * 2.0 ** k for k in range(n)], dtype=torch.float64)
+    e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / float(torch.sqrt(t[0] * t[-1])))
+    x = ((e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0, 1) ** (1 / 2.2)).float()
+    sd = (0.002 + 0.03 * torch.rand(x.shape, generator=gen)).float()
+    flat = (0.6 + 0.4 * torch.rand((c, h, w), generator=gen)).float()
+    flat_std = (0.01 * torch.rand((c, h, w), generator=gen)).float()
+    lut = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.8, 2.2, 2.6)])
+    return x, sd, t, flat, flat_std, lut
+
+
+def _hdr_worker(rank, world, port, out_dir):
+    import contextlib
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.utils.data import DataLoader
+        from clair_torch_amd import _native as nv
+        from clair_torch_amd import ops
+        from clair_torch_amd.common.enums import InterpMode
+        from clair_torch_amd.datasets import ArtefactStack, StackDataset, custom_collate
+        from clair_torch_amd.inference import _staging, compute_hdr_image, hdr_merge
+        from clair_torch_amd.models import ICRFModelDirect
+        from clair_torch_amd.training.losses import gaussian_value_weights
+        from oracle import ct_oracle as oc
+        # host memory stands in for HBM: lift the device checks, keep everything else
+        fake = _OracleBackedLibrary()
+        nv.load = lambda: fake
+        ops._require_device = lambda t, name: None
+        ops._stream = lambda device: None
+        torch.cuda.device = lambda dev: contextlib.nullcontext()
+        _staging.resolve_device = lambda device: torch.device("cpu")
+        hdr_merge.resolve_device = _staging.resolve_device
+        x, sd, t, flat, flat_std, lut = _hdr_scene()
+        h = x.shape[2]
+        r0, r1 = [(0, 5), (5, 11)][rank]
+        model = ICRFModelDirect(icrf=lut, interpolation_mode=InterpMode.LINEAR)
+        ds = StackDataset(x[:, :, r0:r1].contiguous(), t.tolist(), stds=sd[:, :, r0:r1].contiguous())
+        loader = DataLoader(ds, batch_size=4, shuffle=False, collate_fn=custom_collate)     # batches [4, 2]: streaming state
+        ff = ArtefactStack(flat[:, r0:r1].contiguous(), flat_std[:, r0:r1].contiguous())
+        mean, std = compute_hdr_image(loader, "cuda", model, weight_fn=gaussian_value_weights, flat_field_dataset=ff,
+                                      tile=ops.TileGeometry(h_global=h, row_offset=r0))
+        # whole image on one process: oracle merge with the same batch partition, then the oracle's flat-field epilogue
+        m_o, s_o = oc.hdr_merge(x.numpy(), sd.numpy(), t.numpy(), lut.numpy(), "linear", True, [4, 2])
+        m_o, s_o = oc.flatfield_merge(m_o, s_o, flat.numpy(), flat_std.numpy())
+        assert mean.dtype == torch.float64 and std.dtype == torch.float32 and mean.shape == (3, r1 - r0, x.shape[3])
+        assert np.allclose(mean.numpy(), m_o[:, r0:r1], rtol=1e-12, atol=0), np.abs(mean.numpy() - m_o[:, r0:r1]).max()
+        assert np.allclose(std.numpy(), s_o[:, r0:r1], rtol=2e-6, atol=0), np.abs(std.numpy() / s_o[:, r0:r1] - 1).max()
+        # without the all-reduce (group of one) the band's own flat-field mean would be used: must differ
+        mean_solo, _ = compute_hdr_image(loader, "cuda", model, weight_fn=gaussian_value_weights, flat_field_dataset=ff)
+        assert not np.allclose(mean_solo.numpy(), m_o[:, r0:r1], rtol=1e-6, atol=0)
+        open(os.path.join(out_dir, f"hdr_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_compute_hdr_image_with_flat_field_two_ranks(tmp_path):
+    mp.spawn(_hdr_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "hdr_ok0").exists() and (tmp_path / "hdr_ok1").exists()
