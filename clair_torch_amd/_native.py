@@ -90,6 +90,8 @@ def load():
     lib.ct_flatfield_sums.argtypes = [vp, i32, vp, i32, i64, vp, vp]
     lib.ct_flatfield_apply.restype = i32
     lib.ct_flatfield_apply.argtypes = [vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i64, vp]
+    lib.ct_dark_field_blur.restype = i32
+    lib.ct_dark_field_blur.argtypes = [vp, i32, f32, i32, gp, vp, vp, i32, f32, vp, vp, i32, f32, f32, vp, vp, vp]
     lib.ct_video_stats_batch.restype = i32
     lib.ct_video_stats_batch.argtypes = [vp, i32, f32, i32, gp, ip, f32, vp, vp, vp]
     if lib.ct_abi_version() != ABI_VERSION:

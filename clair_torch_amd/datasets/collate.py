@@ -12,8 +12,12 @@ from torch.utils.data._utils.collate import default_collate
 
 def _stack_or_view(tensors):
     first = tensors[0]
-    if not isinstance(first, torch.Tensor) or len(tensors) < 2:
+    if not isinstance(first, torch.Tensor):
         return default_collate(tensors)
+    if len(tensors) == 1:
+        # batch_size 1 (linearization): a view with a leading axis -- no 12-50 MB host copy per frame, and a pinned frame
+        # stays pinned, so its host-to-device copy is a plain DMA
+        return first.unsqueeze(0)
     base = first.untyped_storage().data_ptr()
     step = tensors[1].storage_offset() - first.storage_offset()
     if step < first.numel() or not first.is_contiguous():

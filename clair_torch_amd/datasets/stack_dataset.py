@@ -58,8 +58,8 @@ class StackDataset(Dataset):
 
 class ArtefactStack:
     """In-memory stand-in for the reference's FlatFieldArtefactMapDataset (clair_torch/datasets/base.py:175-259):
-    ``get_matching_artefact_images`` returns the collated 4-tuple ``(indices, value (1,C,H,W), std (1,C,H,W) | None,
-    meta)`` of the single calibration image it holds, whatever frame settings are asked for."""
+    ``get_matching_artefact_images`` returns the collated 4-tuple ``(indices, value (B,C,H,W), std (B,C,H,W) | None,
+    meta)`` with B = the number of frame settings asked for, every entry being the single calibration image it holds."""
 
     def __init__(self, value: torch.Tensor, std: Optional[torch.Tensor] = None):
         if value.ndim != 3:
@@ -67,8 +67,12 @@ class ArtefactStack:
         self.value, self.std = value, std
 
     def get_matching_artefact_images(self, reference_frame_settings_list):
-        std = None if self.std is None else self.std.unsqueeze(0)
-        return torch.tensor([0]), self.value.unsqueeze(0), std, {}
+        # the reference looks one artefact image up per requested frame and collates them (datasets/base.py:225-255):
+        # a batch of B frames gets (B, C, H, W), here B views of the one image held
+        n = max(1, len(reference_frame_settings_list))
+        value = self.value.unsqueeze(0).expand(n, *self.value.shape)
+        std = None if self.std is None else self.std.unsqueeze(0).expand(n, *self.std.shape)
+        return torch.zeros(n, dtype=torch.int64), value, std, {}
 
 
 def synthetic_exposure_stack(n: int, channels: int, height: int, width: int, bits: int = 16, stops_per_step: float = 0.25,

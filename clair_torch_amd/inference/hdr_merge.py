@@ -25,18 +25,21 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
     ``weight_fn``: None = unit weights, anything else = Gaussian weights, scale 30 (hdr_merge.py:95).
     ``flat_field_dataset``: any object with the reference's ``get_matching_artefact_images`` (e.g.
     ``clair_torch_amd.datasets.ArtefactStack``); its image must cover the rows this process holds.
+    ``dark_field_dataset``: likewise; the matched dark fields drive a conditional 3x3 blur of every batch and add their
+    own variance term (inference/dark_field.py; parity unpinned -- the blur is torchvision's, restated).
     ``tile`` / ``group`` (extensions): the rows this process holds of a taller global image (multi-GPU row bands) and
-    the process group over which the flat field's spatial sums are all-reduced.
+    the process group over which the flat field's spatial sums are all-reduced and the blur's halo rows exchanged.
     """
     expect(dataloader, DataLoader, "dataloader")
     expect(device, (str, torch.device), "device")
     expect(icrf_model, ICRFModelBase, "icrf_model", allow_none=True)
     if weight_fn is not None and not callable(weight_fn):
         expect(weight_fn, type(None), "weight_fn")
-    if dark_field_dataset is not None:
-        raise NotImplementedError("dark-field correction is not built (SURVEY 8f row 4: parity unpinned, its blur "
-                                  "lives in torchvision which the reference does not vendor)")
     dev = resolve_device(device)
+    dark = None
+    if dark_field_dataset is not None:  # hdr_merge.py:76-92 (PARITY UNPINNED: the blur is torchvision's, restated)
+        from .dark_field import DarkField
+        dark = DarkField.from_dataset(dark_field_dataset, dataloader.dataset, dev)
     transforms = normalise_transform_list(gpu_transforms)
     lut = interp = None
     if icrf_model is not None:
@@ -48,13 +51,17 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
     if pending is None:
         raise ValueError("dataloader yielded no batches")
     while pending is not None:
-        _, val_batch, std_batch, meta_batch = pending
+        index_batch, val_batch, std_batch, meta_batch = pending
         pending = next(batches, None)
         last = pending is None
         images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
-        if std is not None and layout != "nchw":  # explicit std images come planar: take the generic path
+        if (std is not None or dark is not None) and layout != "nchw":  # explicit std / dark images are planar
             images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
+        if dark is not None:
+            xb, sig = dark.apply(index_batch, images, max_code, std, std_mode, std_value, tile, group)
+            if xb is not None:  # the blurred batch replaces the images; its uncertainty carries both variance terms
+                images, max_code, std, std_mode, std_value = xb, None, sig, "explicit", 0.0
         if state is None and (not last or flat_field_dataset is not None):
             chw = tuple(images.shape[1:]) if layout == "nchw" else (images.shape[3], images.shape[1], images.shape[2])
             state = ops.MergeState(chw, dev, with_variance=std_mode != "none")

@@ -163,9 +163,11 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
 def linearize_frames(frames: torch.Tensor, lut: torch.Tensor, interp: str = "linear", *,
                      std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                      max_code: Optional[float] = None, want_std: bool = True, tile: Optional[TileGeometry] = None,
-                     layout: str = "nchw"):
+                     layout: str = "nchw", out=None):
     """ct_linearize_std on (F,C,H,W) frames -> (lin float32, std float32 | None); every frame is its own batch.
-    ``layout`` "nhwc" / "nhwc_bgr": frames are (F,H,W,C); the outputs are planar (F,C,H,W)."""
+    ``layout`` "nhwc" / "nhwc_bgr": frames are (F,H,W,C); the outputs are planar (F,C,H,W).
+    ``out`` = (lin, std | None): caller-owned contiguous float32 (F,C,H,W) device buffers to write into (the streamed
+    pipeline re-uses its ring slots instead of allocating per launch)."""
     _check_stack(frames, "frames")
     f = frames.shape[0]
     c, h, w = _chw(frames, layout)
@@ -182,8 +184,21 @@ def linearize_frames(frames: torch.Tensor, lut: torch.Tensor, interp: str = "lin
     icrf, lut_keep = _icrf_struct(lut, interp, c)
     frames = frames.contiguous()
     geom = _geometry(frames, tile, layout)
-    lin = torch.empty((f, c, h, w), dtype=torch.float32, device=dev)
-    std_out = torch.empty_like(lin) if want_std else None
+    if out is None:
+        lin = torch.empty((f, c, h, w), dtype=torch.float32, device=dev)
+        std_out = torch.empty_like(lin) if want_std else None
+    else:
+        lin, std_out = out
+        for name, t in (("out[0]", lin), ("out[1]", std_out)):
+            if t is None:
+                continue
+            _require_device(t, name)
+            if t.dtype != torch.float32 or tuple(t.shape) != (f, c, h, w) or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous float32 tensor of shape {(f, c, h, w)}")
+        if want_std and std_out is None:
+            raise ValueError("want_std needs out[1]")
+        if not want_std:
+            std_out = None
     with torch.cuda.device(dev):
         rc = nv.load().ct_linearize_std(_ptr(frames), _DTYPE[frames.dtype], float(max_code or 1.0), f, ctypes.byref(geom),
                                         _ptr(std), _STD[std_mode], float(std_value), ctypes.byref(icrf), _ptr(lin),
@@ -396,6 +411,48 @@ def flatfield_correct(value: torch.Tensor, var_or_std: Optional[torch.Tensor], f
                                           _ptr(flat), _ptr(flat_std), _ptr(flat_mean), _ptr(through), c, plane, _stream(dev))
     nv.check(rc, "ct_flatfield_apply")
     return value, var_or_std
+
+
+# ---- dark-field conditional blur -----------------------------------------------------------------------------------
+def dark_field_blur(stack: torch.Tensor, dark: torch.Tensor, dark_std: Optional[torch.Tensor], *,
+                    std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
+                    max_code: Optional[float] = None, tile: Optional[TileGeometry] = None,
+                    halo: Optional[torch.Tensor] = None, threshold: float = 0.05, alpha: float = 50.0):
+    """ct_dark_field_blur: (xb float32 (B,C,H,W), sigma_eff float32 | None).  ``dark`` / ``dark_std`` are (1|B,C,H,W);
+    ``halo`` (B,C,2,W) holds the global rows above / below a row band (see include/clair_hip.h)."""
+    _check_stack(stack)
+    b, c, h, w = stack.shape
+    dev = stack.device
+    if std is not None:
+        std_mode = "explicit"
+        _require_device(std, "std")
+        if std.shape != stack.shape:
+            raise ValueError("std shape != stack shape")
+        std = std.to(torch.float32).contiguous()
+    stack = stack.contiguous()
+    if stack.dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
+    dark = dark.to(device=dev, dtype=torch.float32).contiguous()
+    if dark.ndim != 4 or dark.shape[0] not in (1, b) or tuple(dark.shape[1:]) != (c, h, w):
+        raise ValueError(f"mask_map batch dimension must be 1 or {b}, got shape {tuple(dark.shape)}")
+    if dark_std is not None:
+        dark_std = dark_std.to(device=dev, dtype=torch.float32).contiguous()
+        if dark_std.shape != dark.shape:
+            raise ValueError("dark_std shape != dark shape")
+    if halo is not None:
+        halo = halo.to(device=dev, dtype=stack.dtype).contiguous()
+        if tuple(halo.shape) != (b, c, 2, w):
+            raise ValueError(f"halo must be (B, C, 2, W) = {(b, c, 2, w)}, got {tuple(halo.shape)}")
+    geom = _geometry(stack, tile)
+    xb = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+    sig = torch.empty_like(xb) if dark_std is not None else None
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_dark_field_blur(_ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), b, ctypes.byref(geom),
+                                          _ptr(halo), _ptr(std), _STD[std_mode], float(std_value), _ptr(dark),
+                                          _ptr(dark_std), dark.shape[0], float(threshold), float(alpha), _ptr(xb), _ptr(sig),
+                                          _stream(dev))
+    nv.check(rc, "ct_dark_field_blur")
+    return xb, sig
 
 
 # ---- streaming video statistics -----------------------------------------------------------------------------------

@@ -221,6 +221,24 @@ int ct_flatfield_apply(void *value_dev, int32_t value_is_f64, int64_t n_frames, 
                        void *stream);
 
 /*
+ * ct_dark_field_blur -- conditional_gaussian_blur(images, dark, threshold, 3, differentiable=True)
+ * (clair_torch/common/general_functions.py:440-486) as compute_hdr_image (inference/hdr_merge.py:76-92,117-126) and
+ * linearize_dataset_generator (inference/linearization.py:73-92,108-116) apply it, together with the per-sample
+ * uncertainty that carries BOTH variance terms of those call sites through the unchanged merge / linearize kernels:
+ *   xb_out      (B, C, H_tile, W) float32 = m blur3x3(x) + (1 - m) x,  m = sigmoid(alpha (dark - threshold))
+ *   std_out     (B, C, H_tile, W) float32 = sqrt(sigma^2 + ((blur(x) - x) alpha m (1 - m) sigma_dark)^2), or NULL
+ *   stack_dev   (B, C, H_tile, W) codes / float32 pixels (NCHW only); std_dev / std_mode / std_value: sigma of the RAW image
+ *   dark_dev, dark_std_dev (dark_batch, C, H_tile, W) float32, dark_batch = 1 (shared) or B (one matched dark field per frame)
+ *   halo_dev    (B, C, 2, W) in the stack's element type: the global rows just above and below the band; required unless
+ *               the band is the whole image (at the global top / bottom the blur reflects instead and ignores that row)
+ * PARITY UNPINNED: the blur is torchvision's GaussianBlur(3, sigma=1), restated from its published algorithm.
+ */
+int ct_dark_field_blur(const void *stack_dev, int32_t dtype, float max_code, int32_t batch, const ct_geometry *geom,
+                       const void *halo_dev, const float *std_dev, int32_t std_mode, float std_value,
+                       const float *dark_dev, const float *dark_std_dev, int32_t dark_batch, float threshold, float alpha,
+                       float *xb_out_dev, float *std_out_dev, void *stream);
+
+/*
  * ct_video_stats_batch -- loop body of compute_video_mean_and_std
  * (clair_torch/inference/inferential_statistics.py:38-47): optional ICRF linearization of a batch of frames and the
  * unweighted WBOMeanVar update (clair_torch/common/statistics.py:213-259), float32 like the reference.

@@ -197,3 +197,70 @@ def video_mean_std(frames, lut, mode, batch_sizes):
             w_a = w
     var = m2_a * (1 / (w_a - 1))
     return mean_a.squeeze(0), torch.sqrt(var.squeeze(0)) / (k ** 0.5)
+
+
+# ---- dark field -- PARITY UNPINNED --------------------------------------------------------------
+# The blur is torchvision.transforms.GaussianBlur(kernel_size=3, sigma=1.0), a third-party dependency the reference does
+# not vendor (version unpinned, pyproject.toml) and this image lacks.  Restated from its published algorithm
+# (torchvision/transforms/_functional_tensor.py: _get_gaussian_kernel1d -> pdf = exp(-0.5 (x / sigma)^2) on
+# linspace(-1, 1, 3), normalised; kernel2d = outer product; reflect padding; depthwise conv2d).  No vector recorded from
+# the reference covers it, so everything below is pinned to nothing but this restatement.
+def gaussian_blur3(image, sigma=1.0):
+    c = image.shape[-3]
+    x = torch.linspace(-1.0, 1.0, 3, dtype=image.dtype)
+    pdf = torch.exp(-0.5 * (x / sigma) ** 2)
+    k1 = pdf / pdf.sum()
+    k2 = torch.mm(k1[:, None], k1[None, :]).expand(c, 1, 3, 3)
+    padded = torch.nn.functional.pad(image, [1, 1, 1, 1], mode="reflect")
+    return torch.nn.functional.conv2d(padded, k2, groups=c)
+
+
+def conditional_gaussian_blur(image, mask_map, threshold=0.05, alpha=50.0):
+    """clair_torch/common/general_functions.py:440-486 with differentiable=True, kernel_size=3."""
+    mask = torch.sigmoid((mask_map - threshold) * alpha)
+    if mask.shape[0] == 1 and image.shape[0] > 1:
+        mask = mask.expand(image.shape[0], -1, -1, -1)
+    return mask * gaussian_blur3(image) + (1 - mask) * image
+
+
+def merge_stack_dark(vals, stds, exposures, lut, dark, dark_std, mode=LINEAR, use_gauss=True, partition=None):
+    """compute_hdr_image with a dark-field dataset (clair_torch/inference/hdr_merge.py:61-128): ``dark`` / ``dark_std``
+    (C,H,W) are matched to every frame of a batch (one copy per frame, datasets/base.py:225-255).  Note the reference
+    rebinds ``images`` to the blurred batch (:90), so both autograd.grad calls differentiate w.r.t. tensors of the
+    blurred graph."""
+    n = vals.shape[0]
+    partition = [n] if partition is None else list(partition)
+    mean_a, w_a, variance, k = 0.0, 0.0, None, 0
+    for b in partition:
+        raw = vals[k:k + b].clone().requires_grad_(True)
+        sd = stds[k:k + b]
+        t = exposures[k:k + b].to(torch.float64).view(-1, 1, 1, 1)
+        k += b
+        d = dark.unsqueeze(0).expand(b, -1, -1, -1).clone().requires_grad_(True)
+        x = conditional_gaussian_blur(raw, d)                                     # :90, images rebound
+        wts = gaussian_weight(x) if use_gauss else torch.ones_like(x)
+        y = (icrf_forward(x, lut, mode) if lut is not None else x) / t
+        w_b = wts.sum(dim=0, keepdim=True)
+        m_b = (wts * y).sum(dim=0, keepdim=True) / (w_b + 1e-6)
+        w_t = w_a + w_b
+        mean = mean_a + (w_b / w_t) * (m_b - mean_a)
+        g = torch.autograd.grad(mean, x, torch.ones_like(mean), retain_graph=True)[0]          # :107-115
+        upd = ((g * sd) ** 2).sum(dim=0, keepdim=True)
+        variance = upd if variance is None else variance + upd
+        gd = torch.autograd.grad(mean, d, torch.ones_like(mean), retain_graph=False)[0]        # :117-126
+        variance = variance + ((gd * dark_std.unsqueeze(0)) ** 2).sum(dim=0, keepdim=True)
+        mean_a, w_a = mean.detach(), w_t.detach()
+    return mean_a.squeeze(0), torch.sqrt(variance.squeeze(0))
+
+
+def linearize_frame_dark(val, std, lut, dark, dark_std, mode=LINEAR):
+    """One iteration of linearize_dataset_generator with a dark field (clair_torch/inference/linearization.py:73-116)."""
+    raw = val.unsqueeze(0).clone().requires_grad_(True)
+    d = dark.unsqueeze(0).clone().requires_grad_(True)
+    x = conditional_gaussian_blur(raw, d)
+    lin = icrf_forward(x, lut, mode)
+    g = torch.autograd.grad(lin, x, torch.ones_like(lin), retain_graph=True)[0]
+    var = (g * std.unsqueeze(0)) ** 2
+    gd = torch.autograd.grad(lin, d, torch.ones_like(lin))[0]
+    var = var + (gd * dark_std.unsqueeze(0)) ** 2
+    return lin.detach().squeeze(0), torch.sqrt(var).detach().squeeze(0)
