@@ -1,8 +1,8 @@
 """ICRF model base class with the reference's interface (clair_torch/models/base.py:17-259).
 
 The curve is a (C, L) float32 LUT.  ``forward`` dispatches on the interpolation mode like the reference, but the
-three samplers are HIP kernels (ct_linearize_fwd / ct_linearize_bwd through a torch.autograd.Function) instead of
-chains of eager indexing ops; the backward returns the analytic image gradient and the LUT gradient, so optimisers
+three samplers are HIP kernels (ct_linearize_fwd / ct_linearize_bwd, registered as the torch.library custom op
+``clair_hip::icrf_forward`` with its autograd formula, clair_torch_amd/torch_ops.py) instead of chains of eager indexing ops; the backward returns the analytic image gradient and the LUT gradient, so optimisers
 and ``torch.autograd.grad`` calls written against the reference keep working.
 
 Reference behaviours kept on purpose: LINEAR and CATMULL pick the LUT row from the flat NCHW position
@@ -14,25 +14,9 @@ from typing import Optional
 import torch
 from torch import nn
 
-from .. import ops
+from .. import torch_ops
 from ..common.enums import INTERP_NAME, InterpMode
 from ..common.typecheck import expect
-
-
-class _IcrfSample(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, image, lut, interp):
-        ctx.interp = interp
-        ctx.save_for_backward(image, lut)
-        return ops.icrf_forward(image, lut, interp)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        image, lut = ctx.saved_tensors
-        need_x = ctx.needs_input_grad[0] and ctx.interp != "lookup"
-        need_lut = ctx.needs_input_grad[1]
-        gx, gl = ops.icrf_backward(image, grad_out, lut, ctx.interp, need_x, need_lut)
-        return gx, gl, None
 
 
 class ICRFModelBase(nn.Module, ABC):
@@ -84,7 +68,8 @@ class ICRFModelBase(nn.Module, ABC):
                                f"{image.device} tensor. clair_torch_amd has no CPU path.")
         if image.ndim != 4:
             raise ValueError(f"image must be (N, C, H, W), got {tuple(image.shape)}")
-        return _IcrfSample.apply(image.to(torch.float32), self._icrf, self.interp_name)
+        # the dispatcher-registered op (clair_hip::icrf_forward): forward kernel + registered autograd formula
+        return torch_ops.icrf_forward(image.to(torch.float32), self._icrf, self.interp_name)
 
     def plot_icrf(self) -> None:
         """Live plotting is UI (out of scope, SURVEY 2 #12): headless no-op kept for call-site compatibility."""

@@ -469,3 +469,34 @@ def test_alias_package_overlays_a_reference_install(tmp_path, monkeypatch):
     for name in [n for n in sys.modules if n.startswith(("clair_torch.metadata", "clair_torch.common.parameters",
                                                           "_clair_torch_reference"))]:
         del sys.modules[name]
+
+
+def test_torch_library_ops_are_registered_with_schemas_and_fake_kernels():
+    """SURVEY 8(b): the entry points are torch.library custom ops (clair_hip::*): schemas, fake (meta) kernels that
+    propagate shapes / dtypes under FakeTensorMode (what torch.compile / export trace through), and the loud refusal
+    of CPU tensors."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from clair_torch_amd import torch_ops  # noqa: F401  (registers the ops)
+    names = ["icrf_forward", "icrf_backward", "hdr_merge", "linearize_std", "pair_residual_sums", "pair_residual_lut_grad"]
+    for n in names:
+        assert hasattr(torch.ops.clair_hip, n), n
+    assert "Tensor? lut" in str(torch.ops.clair_hip.hdr_merge.default._schema)
+    with FakeTensorMode():
+        lut = torch.empty((3, 256))
+        y = torch.ops.clair_hip.icrf_forward(torch.empty((2, 3, 8, 9)), lut, "linear")
+        assert tuple(y.shape) == (2, 3, 8, 9) and y.dtype == torch.float32
+        m, s = torch.ops.clair_hip.hdr_merge(torch.empty((4, 8, 9, 3), dtype=torch.uint16), torch.empty(4, dtype=torch.float64),
+                                             lut, "linear", True, None, "multiplier", 0.05, 65535.0, 0, 0, "nhwc_bgr")
+        assert tuple(m.shape) == (3, 8, 9) and m.dtype == torch.float64 and s.dtype == torch.float32
+        m2, s2 = torch.ops.clair_hip.hdr_merge(torch.empty((4, 3, 8, 9)), torch.empty(4, dtype=torch.float64), None, "linear",
+                                               False, None, "none", 0.0, 0.0)
+        assert tuple(m2.shape) == (3, 8, 9) and s2.numel() == 0
+        lin, sd = torch.ops.clair_hip.linearize_std(torch.empty((5, 3, 8, 9), dtype=torch.uint8), lut, "linear", None,
+                                                    "multiplier", 0.05, 255.0)
+        assert tuple(lin.shape) == (5, 3, 8, 9) and sd.shape == lin.shape
+        sums = torch.ops.clair_hip.pair_residual_sums(torch.empty((6, 3, 8, 9)), torch.empty(7, dtype=torch.int64),
+                                                      torch.empty(7, dtype=torch.int64), torch.empty(7, dtype=torch.float64), lut,
+                                                      "linear", 0.0, 1.0, True, False, "none", 0.0, 0.0, 1)
+        assert tuple(sums.shape) == (7, 3, 5) and sums.dtype == torch.float64
+    with pytest.raises(RuntimeError, match="MI355X"):
+        torch.ops.clair_hip.icrf_forward(torch.zeros((1, 3, 4, 4)), torch.zeros((3, 16)), "linear")

@@ -239,3 +239,28 @@ def test_streamed_pipeline_is_bit_exact_and_ordered(dev, kind, pinned):
         assert len(slow) == n
         # that route normalises with torch's GPU division (1 ulp off the CPU reference on some codes): value to rounding
         assert max(float((a[0] - b[0]).abs().max()) for a, b in zip(slow, got)) < 1e-6
+
+
+def test_torch_library_ops_run_the_kernels(dev):
+    """torch.ops.clair_hip.* (the dispatcher-registered form of the entry points) give the results of the ctypes
+    front-end, and the registered autograd formula of icrf_forward returns the backward kernel's gradients."""
+    from clair_torch_amd import ops, torch_ops  # noqa: F401
+    rng = np.random.default_rng(8)
+    x = torch.from_numpy(rng.random((2, 3, 9, 11), dtype=np.float32)).to(dev)
+    lut = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.8, 2.2, 2.6)]).to(dev)
+    assert torch.equal(torch.ops.clair_hip.icrf_forward(x, lut, "catmull"), ops.icrf_forward(x, lut, "catmull"))
+    xg, lg = x.clone().requires_grad_(True), lut.clone().requires_grad_(True)
+    out = torch.ops.clair_hip.icrf_forward(xg, lg, "linear")
+    g = torch.from_numpy(rng.random(out.shape, dtype=np.float32)).to(dev)
+    gx, gl = torch.autograd.grad(out, (xg, lg), g)
+    rx, rl = ops.icrf_backward(x, g, lut, "linear", True, True)
+    assert torch.equal(gx, rx) and torch.allclose(gl, rl, rtol=1e-5, atol=1e-7)   # LUT gradient: atomics, order-dependent
+    codes = torch.from_numpy(rng.integers(0, 65536, size=(5, 3, 9, 11)).astype(np.uint16)).to(dev)
+    t = torch.tensor([0.001 * 2.0 ** k for k in range(5)], dtype=torch.float64)
+    lut256 = torch.stack([torch.linspace(0, 1, 256) ** p for p in (1.8, 2.2, 2.6)]).to(dev)
+    m, s = torch.ops.clair_hip.hdr_merge(codes, t, lut256, "linear", True, None, "multiplier", 0.05, 65535.0)
+    m2, s2 = ops.hdr_merge_batch(codes, t, lut=lut256, interp="linear", std_mode="multiplier", std_value=0.05)
+    assert torch.equal(m, m2) and torch.equal(s, s2)
+    lin, sd = torch.ops.clair_hip.linearize_std(codes, lut256, "linear", None, "multiplier", 0.05, 65535.0)
+    lin2, sd2 = ops.linearize_frames(codes, lut256, "linear", std_mode="multiplier", std_value=0.05)
+    assert torch.equal(lin, lin2) and torch.equal(sd, sd2)

@@ -143,14 +143,27 @@ int main(int argc, char **argv)
     CK(hipMalloc(&mean2, Q * 8)); CK(hipMalloc(&std2, Q * 4)); CK(hipMalloc(&acc, 6 * 8));
     std::vector<Variant> vs = {
         {"pivot V4 mult", launch_pivot_v<CT_STD_MULTIPLIER>}, {"pivot V4 nostd", launch_pivot_v<CT_STD_NONE>},
-        {"pivot V4 mult one-exposure (compute only)", launch_pivot_nomem<CT_STD_MULTIPLIER>},
+        {"compute-only yardstick (every exposure aliases exposure 0)", launch_pivot_nomem<CT_STD_MULTIPLIER>},
         {"stream V4 (8B/lane)", launch_stream<4>}, {"stream V8 (16B/lane)", launch_stream<8>},
         {"f64 V4 PF2 mult", launch_v<4, 2, CT_STD_MULTIPLIER>}, {"f64 V4 PF2 nostd", launch_v<4, 2, CT_STD_NONE>},
     };
     const char *only = argc > 5 ? argv[5] : nullptr;   // run only the variants whose name contains this (for rocprofv3 --pmc)
     if (only) {
         std::vector<Variant> keep;
-        for (auto &v : vs) if (v.name.find(only) != std::string::npos) keep.push_back(v);
+        // '|'-separated list of substrings
+        std::string pat(only);
+        for (auto &v : vs) {
+            size_t at = 0;
+            bool hit = false;
+            while (at <= pat.size()) {
+                const size_t bar = pat.find('|', at);
+                const std::string one = pat.substr(at, bar == std::string::npos ? std::string::npos : bar - at);
+                if (!one.empty() && v.name.find(one) != std::string::npos) hit = true;
+                if (bar == std::string::npos) break;
+                at = bar + 1;
+            }
+            if (hit) keep.push_back(v);
+        }
         vs = keep;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
