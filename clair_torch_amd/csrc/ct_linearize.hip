@@ -5,9 +5,11 @@
 //                       for LOOKUP/LINEAR), std = sqrt((f'(x) * sigma)^2) = |f'(x) * sigma|.
 //  * ct_linearize_fwd : ICRFModelBase.forward (clair_torch/models/base.py:135-226) on a float32 (N,C,H,W) tensor.
 //  * ct_linearize_bwd : its backward; the (C,L) LUT gradient is a scatter-add of every sample into <= 4 bins,
-//                       privatised per workgroup in LDS (ds_add_f32) and flushed with one global float atomic per
-//                       bin per workgroup (global float atomics run at ~1.3 TB/s chip-wide; C*L*4 B per workgroup
-//                       keeps the flush negligible).
+//                       privatised per workgroup in a float64 LDS histogram (ds_add_f64: 9-21 cycles per wavefront
+//                       instruction on gfx950, against ~190 for ds_add_f32 on any address pattern,
+//                       profiles/r01_lds_atomic_rates.log) and flushed with one global float atomic per bin per
+//                       workgroup (global float atomics run at ~1.3 TB/s chip-wide; C*L*4 B per workgroup keeps the
+//                       flush negligible).
 //
 // Roofline: HBM (sizeof(T) read + 4 or 8 B written per sample).  No reuse between workgroups, so no XCD remap.
 #include <algorithm>

@@ -126,7 +126,13 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
         raise ValueError(f"unknown std_mode {std_mode}")
     if stack.dtype != torch.float32 and max_code is None:
         max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
-    exposure_dev = exposures.to(device=dev, dtype=torch.float64).contiguous()
+    if exposures.is_cuda or dev.type != "cuda":
+        exposure_dev = exposures.to(device=dev, dtype=torch.float64).contiguous()
+    else:
+        # A copy from pageable host memory blocks the host until the stream reaches it -- i.e. until the previous merge
+        # kernel has finished -- which serialises this call's host work with the device (measured: 1.18 ms per
+        # compute_hdr_image call against a 0.95 ms kernel).  Staged through pinned memory the copy is asynchronous.
+        exposure_dev = exposures.to(torch.float64).contiguous().pin_memory().to(dev, non_blocking=True)
     if exposure_dev.numel() != b:
         raise ValueError(f"{exposure_dev.numel()} exposure times for a batch of {b}")
     icrf, lut_keep = _icrf_struct(lut, interp, c)
@@ -260,20 +266,20 @@ class PairList:
         self.i = i_cpu.to(torch.int32).to(device)
         self.j = j_cpu.to(torch.int32).to(device)
         self.ratio = ratio.to("cpu", torch.float64).to(device)
-        offsets, samples, codes = [0], [], []
-        il, jl = i_cpu.tolist(), j_cpu.tolist()
-        for n in range(n_images):
-            for p, (a, b) in enumerate(zip(il, jl)):
-                if a == n:
-                    samples.append(b)
-                    codes.append(p)
-                elif b == n:
-                    samples.append(a)
-                    codes.append(~p)
-            offsets.append(len(samples))
-        self.part_off = torch.tensor(offsets, dtype=torch.int32, device=device)
-        self.part_sample = torch.tensor(samples or [0], dtype=torch.int32, device=device)
-        self.part_pair = torch.tensor(codes or [0], dtype=torch.int32, device=device)
+        # CSR over samples, entries of a sample in ascending pair order: (partner, p) when the sample is the pair's first
+        # image, (partner, ~p) when it is the second.  Vectorised: one stable sort of the 2P (owner, pair) keys.
+        p_idx = torch.arange(self.n_pairs, dtype=torch.int64)
+        owner = torch.cat([i_cpu, j_cpu])
+        partner = torch.cat([j_cpu, i_cpu])
+        code = torch.cat([p_idx, ~p_idx])
+        order = torch.argsort(owner * max(self.n_pairs, 1) + torch.cat([p_idx, p_idx]), stable=True)
+        counts = torch.bincount(owner, minlength=n_images) if self.n_pairs else torch.zeros(n_images, dtype=torch.int64)
+        offsets = torch.zeros(n_images + 1, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(counts[:n_images], dim=0)
+        samples, codes = partner[order], code[order]
+        self.part_off = offsets.to(torch.int32).to(device)
+        self.part_sample = (samples if self.n_pairs else torch.zeros(1, dtype=torch.int64)).to(torch.int32).to(device)
+        self.part_pair = (codes if self.n_pairs else torch.zeros(1, dtype=torch.int64)).to(torch.int32).to(device)
         self._workspace = {}
 
     def workspace(self, channels: int) -> torch.Tensor:
