@@ -32,7 +32,9 @@ def pytest_sessionfinish(session, exitstatus):
             w["norm"], w["elem"] = max(w["norm"], o["norm"]), max(w["elem"], o["elem"])
         out_dir = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "parity_observed.json"), "w") as fh:
+        import torch
+        name = "parity_observed.json" if torch.cuda.is_available() else "parity_observed_cpu.json"
+        with open(os.path.join(out_dir, name), "w") as fh:
             json.dump(sorted(worst.values(), key=lambda o: -o["elem"] / o["elem_tol"]), fh, indent=1)
     except Exception as exc:  # never fail a run over the report
         print(f"parity report not written: {exc}", file=sys.stderr)

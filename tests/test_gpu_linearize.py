@@ -124,7 +124,7 @@ def test_backward_matches_eager_autograd(dev, mode):
     lut_grad = torch.stack([p.grad for p in model.direct_params]).cpu()
     assert_parity(lut_grad.numpy(), grads[0].numpy(), rtol=1e-5, norm_tol=1e-6, what="lut grad")
     if mode != "lookup":
-        tol = dict(rtol=1e-5, norm_tol=1e-6) if mode == "linear" else dict(rtol=1e-4, norm_tol=2e-5)
+        tol = dict(rtol=1e-5, norm_tol=1e-6) if mode == "linear" else dict(rtol=3e-5, norm_tol=1e-5)  # CATMULL basis backward cancels ~100x in float32 (observed 1.1e-5 / 3.4e-6)
         assert_parity(xd.grad.cpu().numpy(), grads[1].numpy(), what="image grad", **tol)
 
 

@@ -15,8 +15,11 @@ from _util import PARTITIONS, assert_parity, golden, std_for
 
 pytestmark = pytest.mark.gpu
 
-ELEM_TOL = {"linear": 2e-5, "nomodel": 1e-5, "lookup": 1e-4, "catmull": 1e-4}
-NORM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 1e-5, "catmull": 2e-5}
+# element-wise against the GOLDEN vectors: what the reference's own float32 autograd noise leaves (observed worst, this
+# round: linear 4.6e-6, no model 4.0e-7, lookup 1.2e-5, catmull 2.0e-5 -- profiles/r02_parity_observed.json); against the
+# float64 oracle every comparison in this file holds rtol 1e-5
+ELEM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 3e-5, "catmull": 4e-5}
+NORM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 1e-5, "catmull": 1e-5}
 
 
 @pytest.fixture(scope="module")
@@ -101,14 +104,14 @@ def test_config_c1_through_public_api(dev):
                                       gpu_transforms=[CastTo("float32"), Normalize(max_val=255, min_val=0)])
         assert mean.dtype == torch.float64 and std.dtype == torch.float32 and mean.shape == (3, 256, 256)
         assert_parity(mean.cpu().numpy(), g[f"c1_{pname}_mean"], rtol=1e-5, norm_tol=1e-6, what="c1 mean")
-        assert_parity(std.cpu().numpy(), g[f"c1_{pname}_std"], norm_tol=1e-5, elem_tol=5e-5, what="c1 std")
+        assert_parity(std.cpu().numpy(), g[f"c1_{pname}_std"], norm_tol=1e-5, elem_tol=1e-5, what="c1 std")
     # reference-style: float images, explicit std tensors
     x = torch.from_numpy(oc.normalize_codes(g["c1_codes"]))
     ds = StackDataset(x, g["c1_exposures"].tolist(), missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05)
     loader = DataLoader(ds, batch_size=4, shuffle=False, collate_fn=custom_collate)
     mean, std = compute_hdr_image(loader, torch.device("cuda:0"), model, weight_fn=gaussian_value_weights)
     assert_parity(mean.cpu().numpy(), g["c1_44_mean"], rtol=1e-5, norm_tol=1e-6, what="c1 mean (float path)")
-    assert_parity(std.cpu().numpy(), g["c1_44_std"], norm_tol=1e-5, elem_tol=5e-5, what="c1 std (float path)")
+    assert_parity(std.cpu().numpy(), g["c1_44_std"], norm_tol=1e-5, elem_tol=1e-5, what="c1 std (float path)")
 
 
 @pytest.mark.parametrize("shape", [(5, 3, 37, 53), (7, 1, 64, 40), (4, 3, 31, 8), (9, 4, 16, 24)])

@@ -62,7 +62,7 @@ def test_pair_sums_vs_golden(dev, as_codes, sname, mode):
             mean, sd, err = spatial_statistics(sums, centered, sname != "none")
             key = f"train_{sname}_{mode}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
             assert_parity(mean.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " mean")
-            assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=2e-5, norm_tol=5e-6, what=key + " std")
+            assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=1e-5, norm_tol=2e-6, what=key + " std")
             if sname != "none":
                 assert_parity(err.cpu().numpy(), g[key + "_spatial_err"], rtol=1e-5, norm_tol=2e-6, what=key + " err")
 
@@ -84,8 +84,9 @@ def test_linearity_loss_and_lut_gradient(dev, mode, rel):
     assert_parity(spatial.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " spatial")
     grad = torch.autograd.grad(lin.sum(), lut)[0]
     assert grad.shape == lut.shape and grad.dtype == torch.float32
-    # the reference accumulates this gradient in float32 through index_put; element-wise it is only good to ~1e-4
-    assert_parity(grad.cpu().numpy(), g[key + "_lingrad"], norm_tol=2e-5, elem_tol=2e-4, what=key + " lingrad")
+    # the reference accumulates this gradient in float32 through index_put (thread-order noise up to 2.5e-5 between two
+    # runs of the reference itself on the arrays' smallest entries); observed against it here: 5.1e-7 element-wise
+    assert_parity(grad.cpu().numpy(), g[key + "_lingrad"], norm_tol=2e-6, elem_tol=1e-5, what=key + " lingrad")
     # with uncertainty images but without uncertainty weighting the loss is unchanged (losses.py:93-100)
     lin2, _ = linearity_loss(lut, stack, pairs, interp=mode, lower=1 / 255, upper=254 / 255, use_relative=rel,
                              use_unc_weight=False, std_mode="multiplier", std_value=0.05)
@@ -108,7 +109,7 @@ def test_uncertainty_weighted_loss_and_gradient(dev, mode, rel):
     assert_parity(lin.detach().cpu().numpy(), g[key + "_linloss"], rtol=1e-5, norm_tol=2e-6, what=key + " linloss")
     assert_parity(spatial.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key + " spatial")
     grad = torch.autograd.grad(lin.sum(), lut)[0]
-    assert_parity(grad.cpu().numpy(), g[key + "_lingrad"], norm_tol=5e-5, elem_tol=5e-4, what=key + " lingrad")
+    assert_parity(grad.cpu().numpy(), g[key + "_lingrad"], norm_tol=2e-6, elem_tol=1e-5, what=key + " lingrad")
 
 
 def test_train_icrf_uncertainty_weighted_run(dev):
@@ -169,7 +170,7 @@ def test_lut_gradient_vs_eager_oracle_large(dev, h, w, kind):
     grad = torch.autograd.grad(lin.sum(), lut)[0]
     assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="spatial")
     assert_parity(lin.detach().cpu().numpy(), lin_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="lin loss")
-    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="lut grad")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=1e-5, what="lut grad")
     # tiles: sums and LUT gradients are additive over row bands when the global geometry is passed
     kw = dict(lut=lut.detach(), interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False,
               max_code=max_code)
@@ -220,7 +221,7 @@ def test_many_exposures_narrow_tiles(dev, mode):
                              use_unc_weight=False)
     grad = torch.autograd.grad(lin.sum(), lut)[0]
     assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="spatial")
-    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="lut grad")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=1e-5, what="lut grad")
 
 
 @pytest.mark.parametrize("sname", ["none", "multiplier"])
@@ -246,7 +247,7 @@ def test_measure_linearity_api(dev, sname, mname):
             key = f"meas_{sname}_{mname}_{'rel' if rel else 'abs'}_{'unc' if unc else 'nounc'}"
             assert np.array_equal(ratio.cpu().numpy(), g[key + "_ratio"])
             assert_parity(mean.cpu().numpy(), g[key + "_spatial"], rtol=1e-5, norm_tol=2e-6, what=key)
-            assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=2e-5, norm_tol=5e-6, what=key + " std")
+            assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=1e-5, norm_tol=2e-6, what=key + " std")
             if sname == "none":
                 assert err is None
             else:
@@ -347,4 +348,4 @@ def test_config_c3_full_shape(dev):
     grad = torch.autograd.grad(lin.sum(), lut)[0]
     assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="C3 band spatial means")
     assert_parity(lin.detach().cpu().numpy(), lin_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="C3 band linearity loss")
-    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-5, elem_tol=2e-4, what="C3 band LUT gradient")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=1e-5, what="C3 band LUT gradient")
