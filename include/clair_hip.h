@@ -117,6 +117,20 @@ int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int
                        const ct_icrf *icrf, int32_t weight_mode, double *mean_state_dev, float *sumw_state_dev,
                        float *var_state_dev, void *mean_out_dev, float *std_out_dev, uint32_t flags, void *stream);
 
+/*
+ * Host-side proofs behind the folded integer paths (no device work; results cached per argument set):
+ *   ct_norm_constants        fma(u, hi, u * lo) == the reference's float32 u / max_code for EVERY code
+ *                            (clair_torch/common/general_functions.py:377) -- else CT_ERR_UNSUPPORTED
+ *   ct_index_constants       the folded LUT coordinate has the reference's floor and round-half-even for every code
+ *                            (clair_torch/models/base.py:146,166)
+ *   ct_pivot_index_constants floor(u (L-1) / max_code) == (u * index_mul) >> 32 (or == u when *index_mul == 0) for every
+ *                            code, with step = max_code / (L-1) an integer (what ct::merge_pivot_kernel addresses its
+ *                            table with)
+ */
+int ct_norm_constants(float max_code, float *hi, float *lo);
+int ct_index_constants(float max_code, int n_points, float *hi, float *lo);
+int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
+
 /* Diagnostics: a static string naming the kernel ct_hdr_merge_batch dispatches for these arguments. */
 const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, int32_t interp, int32_t n_points, uint32_t flags);
 
