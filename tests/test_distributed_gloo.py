@@ -263,3 +263,32 @@ def _hdr_worker(rank, world, port, out_dir):
 def test_sharded_compute_hdr_image_with_flat_field_two_ranks(tmp_path):
     mp.spawn(_hdr_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "hdr_ok0").exists() and (tmp_path / "hdr_ok1").exists()
+
+
+# ---- dark-field halo exchange between row bands ---------------------------------------------------------------------
+def _halo_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clair_torch_amd import ops
+        from clair_torch_amd.inference.dark_field import exchange_halo
+        gen = torch.Generator().manual_seed(5)
+        whole = torch.rand((4, 3, 13, 6), generator=gen)
+        bands = [(0, 4), (4, 9), (9, 13)]
+        r0, r1 = bands[rank]
+        halo = exchange_halo(whole[:, :, r0:r1].contiguous(), ops.TileGeometry(h_global=13, row_offset=r0))
+        assert halo.shape == (4, 3, 2, 6)
+        if r0 > 0:
+            assert torch.equal(halo[:, :, 0], whole[:, :, r0 - 1])      # the row just above the band
+        if r1 < 13:
+            assert torch.equal(halo[:, :, 1], whole[:, :, r1])          # the row just below
+        assert exchange_halo(whole, None) is None                       # untiled: nothing to exchange
+        open(os.path.join(out_dir, f"halo_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dark_field_halo_exchange_three_ranks(tmp_path):
+    mp.spawn(_halo_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert all((tmp_path / f"halo_ok{r}").exists() for r in range(3))
