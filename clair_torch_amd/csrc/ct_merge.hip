@@ -424,6 +424,9 @@ __device__ __forceinline__ uint32_t code_to_interval(const Packet<T, V> &pk, uin
 // One packet through a buffer descriptor based at `base` (wave-uniform) + a 32-bit per-thread byte offset:
 // buffer_load_* v, v_offset, s[descriptor], 0 offen.  The descriptor spans 4 GiB from the base, so the offset (an
 // element index inside ONE image times the element size) must stay below that -- the callers check.
+#ifndef CT_STACK_LOAD_AUX
+#define CT_STACK_LOAD_AUX 0  // MUBUF cache-policy bits of the stack loads (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
 template <typename P>
 __device__ __forceinline__ P load_buffer(uint64_t base, uint32_t offset)
 {
@@ -431,22 +434,22 @@ __device__ __forceinline__ P load_buffer(uint64_t base, uint32_t offset)
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, 0xffffffff, 0x00020000 /* gfx9 raw dword format */);
     P out;
     if constexpr (sizeof(P) == 1) {
-        const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(rsrc, offset, 0, 0);
+        const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(rsrc, offset, 0, CT_STACK_LOAD_AUX);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else if constexpr (sizeof(P) == 2) {
-        const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(rsrc, offset, 0, 0);
+        const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(rsrc, offset, 0, CT_STACK_LOAD_AUX);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else if constexpr (sizeof(P) == 4) {
-        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offset, 0, 0);
+        const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offset, 0, CT_STACK_LOAD_AUX);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else if constexpr (sizeof(P) == 8) {
         typedef uint32_t vec_t __attribute__((ext_vector_type(2)));
-        const vec_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, 0);
+        const vec_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, offset, 0, CT_STACK_LOAD_AUX);
         __builtin_memcpy(&out, &v, sizeof(P));
     } else {
         static_assert(sizeof(P) == 16, "packets are at most 16 bytes");
         typedef uint32_t vec_t __attribute__((ext_vector_type(4)));
-        const vec_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offset, 0, 0);
+        const vec_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offset, 0, CT_STACK_LOAD_AUX);
         __builtin_memcpy(&out, &v, sizeof(P));
     }
     return out;
