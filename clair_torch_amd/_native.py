@@ -38,7 +38,7 @@ class Icrf(ctypes.Structure):
 class PairParams(ctypes.Structure):
     _fields_ = [("lower", ctypes.c_float), ("upper", ctypes.c_float), ("weight_scale", ctypes.c_float),
                 ("use_relative", ctypes.c_int32), ("use_uncertainty_weighting", ctypes.c_int32),
-                ("std_mode", ctypes.c_int32), ("std_value", ctypes.c_float)]
+                ("std_mode", ctypes.c_int32), ("std_value", ctypes.c_float), ("pair_band", ctypes.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):

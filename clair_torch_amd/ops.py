@@ -250,10 +250,10 @@ def icrf_backward(x: torch.Tensor, grad_out: torch.Tensor, lut: torch.Tensor, in
 
 
 # ---- exposure-pair linearity residual (training / measure_linearity) -----------------------------------------
-def _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value, weight_scale=10.0):
+def _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value, weight_scale=10.0, pair_band=0):
     return nv.PairParams(lower=float(lower), upper=float(upper), weight_scale=float(weight_scale),
                          use_relative=int(bool(use_relative)), use_uncertainty_weighting=int(bool(use_unc_weight)),
-                         std_mode=_STD[std_mode], std_value=float(std_value))
+                         std_mode=_STD[std_mode], std_value=float(std_value), pair_band=int(pair_band))
 
 
 class PairList:
@@ -266,6 +266,9 @@ class PairList:
         self.i = i_cpu.to(torch.int32).to(device)
         self.j = j_cpu.to(torch.int32).to(device)
         self.ratio = ratio.to("cpu", torch.float64).to(device)
+        # band of the list: every pair has 0 < j - i <= band (0 when some pair has j <= i): the hint of ct_pair_params
+        distance = j_cpu - i_cpu
+        self.band = int(distance.max()) if self.n_pairs and int(distance.min()) > 0 else 0
         # CSR over samples, entries of a sample in ascending pair order: (partner, p) when the sample is the pair's first
         # image, (partner, ~p) when it is the second.  Vectorised: one stable sort of the 2P (owner, pair) keys.
         p_idx = torch.arange(self.n_pairs, dtype=torch.int64)
@@ -335,9 +338,10 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
                            lower: float, upper: float, use_relative: bool, max_code: Optional[float] = None,
                            tile: Optional[TileGeometry] = None, use_unc_weight: bool = False,
                            std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
-                           smean: Optional[torch.Tensor] = None):
+                           smean: Optional[torch.Tensor] = None, lane_kernel: bool = True):
     """ct_pair_residual_bwd -> (C, L) float64 LUT gradient of sum_pc coef_pc * D_pc * mean_pc (coef = dL/dmean / D).
-    With ``use_unc_weight`` and uncertainties the weights depend on the LUT and ``smean`` (P,C) is required."""
+    With ``use_unc_weight`` and uncertainties the weights depend on the LUT and ``smean`` (P,C) is required.
+    ``lane_kernel=False`` withholds the pair list's band hint, i.e. forces the generic backward kernel (tests)."""
     _check_stack(stack)
     n, c, _, _ = stack.shape
     dev = stack.device
@@ -351,7 +355,8 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
         max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
     icrf, lut_keep = _icrf_struct(lut, interp, c)
     geom = _geometry(stack, tile)
-    prm = _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value)
+    prm = _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value,
+                       pair_band=pairs.band if lane_kernel else 0)
     if std_mode != "none":
         if smean is None:
             raise ValueError("the uncertainty-weighted backward needs the forward's spatial means")

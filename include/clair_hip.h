@@ -167,6 +167,11 @@ typedef struct ct_pair_params {
     int32_t use_uncertainty_weighting;  /* add 1 / (err + 1e-6) to the weights (losses.py:96) */
     int32_t std_mode;                   /* CT_STD_*: source of sigma for the linearized std |f'(x) sigma| */
     float std_value;
+    int32_t pair_band;                  /* backward only, a hint: 0 = nothing known; B > 0 = the caller promises that every
+                                           pair (i, j) of the list has 0 < j - i <= B (get_valid_exposure_pairs on a sorted
+                                           exposure series with a ratio limit gives such a band).  Enables the
+                                           lane-per-sample backward for n_images <= 64; the promise is verified on the
+                                           device and a broken one only costs the fast path. */
 } ct_pair_params;
 
 /*

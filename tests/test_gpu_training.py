@@ -328,6 +328,11 @@ def test_config_c3_full_shape(dev):
     gen = torch.Generator().manual_seed(3)
     coef = (torch.rand((pairs.n_pairs, c), generator=gen, dtype=torch.float64) * 1e-6).to(dev)
     g_whole = ops.pair_residual_lut_grad(codes, pairs, coef, **kw)
+    # C3's list is a band (16 of 64 samples, 888 of 1024 lane-steps filled): g_whole came from the lane <-> sample kernel;
+    # the generic pair-walk kernel on the same launch arguments must agree (float32 vs float64 partner accumulation)
+    assert pairs.band == 16
+    g_generic = ops.pair_residual_lut_grad(codes, pairs, coef, lane_kernel=False, **kw)
+    assert_parity(g_whole.cpu().numpy(), g_generic.cpu().numpy(), norm_tol=1e-7, elem_tol=1e-5, what="C3 LUT gradient: lane kernel = generic kernel")
     bands = ((0, 701), (701, h))
     parts = [ops.pair_residual_sums(codes[:, :, r0:r1].contiguous(), pairs, level=1,
                                     tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw) for r0, r1 in bands]
@@ -349,3 +354,79 @@ def test_config_c3_full_shape(dev):
     assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="C3 band spatial means")
     assert_parity(lin.detach().cpu().numpy(), lin_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="C3 band linearity loss")
     assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=1e-5, what="C3 band LUT gradient")
+
+
+@pytest.mark.parametrize("interp", ["linear", "catmull", "lookup"])
+@pytest.mark.parametrize("relative", [True, False])
+@pytest.mark.parametrize("n,stops,h,w,kind", [(64, 0.125, 24, 64, "u16"), (64, 0.125, 13, 37, "float"),
+                                              (57, 0.2, 16, 48, "u8"), (64, 0.15, 10, 128, "u16")])
+def test_lane_backward_kernel(dev, interp, relative, n, stops, h, w, kind):
+    """The lane <-> sample backward (band pair lists, N <= 64) against the eager float64 oracle and against the generic
+    pair-walk kernel: whole-tile / ragged (scalar staging) / uint8 / odd band (stops 0.15 -> band 13, rounded up with an
+    all-zero step), every interpolation mode, relative and absolute residual."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from oracle import ct_oracle as oc
+    from oracle import eager_torch as oe
+    gen = torch.Generator().manual_seed(n + h)
+    c = 3
+    t = torch.tensor([0.001 * 2.0 ** (k * stops) for k in range(n)], dtype=torch.float64)
+    e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / float(torch.sqrt(t[0] * t[-1])))
+    x = ((e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0, 1) ** (1 / 2.2)).float()
+    x = (x + 0.01 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    max_code = None
+    if kind != "float":
+        max_code = 65535 if kind == "u16" else 255
+        codes = torch.round(x * max_code).to(torch.int32).numpy().astype(np.uint16 if kind == "u16" else np.uint8)
+        x = torch.from_numpy(oc.normalize_codes(codes))
+        dev_x = torch.from_numpy(codes).to(dev)
+    else:
+        dev_x = x.to(dev)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n, dev)
+    assert pairs.band >= 1 and pairs.n_pairs >= 0.65 * ((pairs.band + 1) // 2 * 2) * 64, "case must be lane-eligible"
+    lut0 = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.9, 2.2, 2.5)])
+    coef = (torch.rand((pairs.n_pairs, c), generator=gen, dtype=torch.float64) * 1e-4)
+    kw = dict(lut=lut0.to(dev), interp=interp, lower=1 / 255, upper=254 / 255, use_relative=relative,
+              use_unc_weight=False, max_code=max_code)
+    g_lane = ops.pair_residual_lut_grad(dev_x, pairs, coef.to(dev), **kw)
+    g_generic = ops.pair_residual_lut_grad(dev_x, pairs, coef.to(dev), lane_kernel=False, **kw)
+    assert_parity(g_lane.cpu().numpy(), g_generic.cpu().numpy(), norm_tol=5e-7, elem_tol=1e-5, what="lane = generic")
+    if interp == "lookup":  # no LUT gradient in the reference for LOOKUP (index lookup): kernel-against-kernel only
+        return
+    # the oracle, through the same autograd route train_icrf takes (linearity_loss -> ct_pair_residual_bwd)
+    from clair_torch_amd.training import linearity_loss
+    lo = lut0.clone().requires_grad_(True)
+    _, lin_o, sp_o = oe.training_loss(x, None, t, lo, interp, 0.25, 1 / 255, 254 / 255, relative, False)
+    grad_o = torch.autograd.grad(lin_o.sum(), lo)[0]
+    lut = lut0.to(dev).requires_grad_(True)
+    lin, sp = linearity_loss(lut, dev_x, pairs, interp=interp, lower=1 / 255, upper=254 / 255, use_relative=relative,
+                             use_unc_weight=False, max_code=max_code)
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="lane: spatial means")
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=2e-5, what="lane: LUT gradient vs oracle")
+
+
+def test_lane_backward_broken_promise_falls_back(dev):
+    """A band hint smaller than the list's real band (or a list with a pair repeated) must not change the result: the
+    entries kernel detects it and the generic kernel does the work."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    gen = torch.Generator().manual_seed(9)
+    n, c, h, w = 64, 3, 8, 64
+    t = torch.tensor([0.001 * 2.0 ** (k * 0.125) for k in range(n)], dtype=torch.float64)
+    x = torch.rand((n, c, h, w), generator=gen).to(dev)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n, dev)
+    lut = torch.stack([torch.linspace(0, 1, 64) ** p for p in (1.9, 2.2, 2.5)]).to(dev)
+    coef = (torch.rand((pairs.n_pairs, c), generator=gen, dtype=torch.float64) * 1e-4).to(dev)
+    kw = dict(lut=lut, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False)
+    good = ops.pair_residual_lut_grad(x, pairs, coef, lane_kernel=False, **kw)
+    pairs.band = 14  # a lie: the list's band is 16
+    lied = ops.pair_residual_lut_grad(x, pairs, coef, **kw)
+    # the generic kernel's float64 atomics land in a run-dependent order (~1e-16); the lane kernel differs from it by
+    # ~1e-9 (float32 partner sums), so 1e-12 also proves WHICH kernel produced the result
+    assert_parity(lied.cpu().numpy(), good.cpu().numpy(), rtol=1e-9, norm_tol=1e-12, what="broken band promise -> generic kernel")
+    pairs.band = 16
+    lane = ops.pair_residual_lut_grad(x, pairs, coef, **kw)
+    assert not torch.equal(lane, good) and float((lane - good).norm() / good.norm()) < 1e-6

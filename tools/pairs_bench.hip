@@ -4,6 +4,7 @@
 //                         tools/pairs_bench.hip clair_torch_amd/csrc/ct_api.cpp -o tools/pairs_bench
 #include "../clair_torch_amd/csrc/ct_pairs.hip"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -117,35 +118,56 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    float ms_f = 0, ms_b = 0;
-    for (int rep = 0; rep < reps + 1; ++rep) {
-        CHECK(hipMemset(d_sums, 0, (size_t)P * C * 5 * 8));
-        CHECK(hipMemset(d_grad, 0, (size_t)C * L * 8));
-        CHECK(hipEventRecord(e0));
-        int rc = ct_pair_residual_fwd(stack, CT_DTYPE_U16, 65535.0f, N, &g, nullptr, &icrf, d_i, d_j, d_r, P, &prm, 0,
-                                      nullptr, d_sums, nullptr);
-        CHECK(hipEventRecord(e1));
-        CHECK(hipEventSynchronize(e1));
-        float t;
-        CHECK(hipEventElapsedTime(&t, e0, e1));
-        if (rc) fprintf(stderr, "fwd rc=%d\n", rc);
-        if (rep) ms_f += t;
-        CHECK(hipEventRecord(e0));
-        rc = ct_pair_residual_bwd(stack, CT_DTYPE_U16, 65535.0f, N, &g, nullptr, &icrf, d_r, P, d_off, d_ps, d_pp, &prm,
-                                  d_coef, nullptr, d_grad, d_ws, ws_bytes, nullptr);
-        CHECK(hipEventRecord(e1));
-        CHECK(hipEventSynchronize(e1));
-        CHECK(hipEventElapsedTime(&t, e0, e1));
-        if (rc) fprintf(stderr, "bwd rc=%d\n", rc);
-        if (rep) ms_b += t;
+    // the backward twice: without the band hint (generic kernel) and with it (lane <-> sample kernel when eligible)
+    int band = 0;
+    for (int p = 0; p < P; ++p) band = std::max(band, pj[p] - pi[p]);
+    std::vector<double> grad_ref;
+    const char *pick = getenv("PAIRS_BENCH_VARIANT");  // "generic" / "lane": only that one (for rocprofv3 --pmc)
+    for (int variant = 0; variant < 2; ++variant) {
+        if (pick && ((variant == 0) != (pick[0] == 'g'))) continue;
+        prm.pair_band = variant == 0 ? 0 : band;
+        float ms_f = 0, ms_b = 0;
+        for (int rep = 0; rep < reps + 1; ++rep) {
+            CHECK(hipMemset(d_sums, 0, (size_t)P * C * 5 * 8));
+            CHECK(hipMemset(d_grad, 0, (size_t)C * L * 8));
+            CHECK(hipEventRecord(e0));
+            int rc = ct_pair_residual_fwd(stack, CT_DTYPE_U16, 65535.0f, N, &g, nullptr, &icrf, d_i, d_j, d_r, P, &prm, 0,
+                                          nullptr, d_sums, nullptr);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float t;
+            CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (rc) fprintf(stderr, "fwd rc=%d\n", rc);
+            if (rep) ms_f += t;
+            CHECK(hipEventRecord(e0));
+            rc = ct_pair_residual_bwd(stack, CT_DTYPE_U16, 65535.0f, N, &g, nullptr, &icrf, d_r, P, d_off, d_ps, d_pp, &prm,
+                                      d_coef, nullptr, d_grad, d_ws, ws_bytes, nullptr);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (rc) fprintf(stderr, "bwd rc=%d\n", rc);
+            if (rep) ms_b += t;
+        }
+        CHECK(hipGetLastError());
+        std::vector<double> sums((size_t)P * C * 5), grad((size_t)C * L);
+        CHECK(hipMemcpy(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(grad.data(), d_grad, grad.size() * 8, hipMemcpyDeviceToHost));
+        double cs = 0, cg = 0;
+        for (double v : sums) cs += v;
+        for (double v : grad) cg += fabs(v);
+        printf("N=%d S=%d P=%d band hint %2d:  fwd %.3f ms  bwd %.3f ms   (checksums: sums %.9e  |grad| %.9e)\n", N, S, P,
+               prm.pair_band, ms_f / reps, ms_b / reps, cs, cg);
+        if (variant == 0) {
+            grad_ref = grad;
+        } else if (!grad_ref.empty()) {
+            double num = 0, den = 0, worst = 0;
+            for (size_t k = 0; k < grad.size(); ++k) {
+                num += (grad[k] - grad_ref[k]) * (grad[k] - grad_ref[k]);
+                den += grad_ref[k] * grad_ref[k];
+                if (grad_ref[k] != 0.0) worst = fmax(worst, fabs(grad[k] - grad_ref[k]) / fabs(grad_ref[k]));
+            }
+            printf("lane vs generic LUT gradient: norm-wise %.3g, worst element %.3g\n", sqrt(num / fmax(den, 1e-300)), worst);
+        }
     }
-    std::vector<double> sums((size_t)P * C * 5), grad((size_t)C * L);
-    CHECK(hipMemcpy(sums.data(), d_sums, sums.size() * 8, hipMemcpyDeviceToHost));
-    CHECK(hipMemcpy(grad.data(), d_grad, grad.size() * 8, hipMemcpyDeviceToHost));
-    double cs = 0, cg = 0;
-    for (double v : sums) cs += v;
-    for (double v : grad) cg += fabs(v);
-    printf("N=%d S=%d P=%d  fwd %.3f ms  bwd %.3f ms   (checksums: sums %.9e  |grad| %.9e)\n", N, S, P, ms_f / reps,
-           ms_b / reps, cs, cg);
     return 0;
 }

@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_pairs
 rm -rf $O && mkdir -p $O
 cd $R
+export PAIRS_BENCH_VARIANT=${1:-generic}
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
   -d $O/p1 --output-format csv -- ./tools/pairs_bench > $O/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA \
