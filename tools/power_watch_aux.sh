@@ -32,6 +32,6 @@ PY
 }
 for pass in 1 2; do
   for a in "$@"; do
-    run "aux${a}_pass$pass" ./tools/merge_bench_aux$a 3500 "pivot V4 mult"
+    run "${a}_pass$pass" ./tools/merge_bench_aux$a 3500 "pivot V4 mult"
   done
 done
