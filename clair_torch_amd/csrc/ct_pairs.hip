@@ -262,8 +262,11 @@ __device__ __forceinline__ float sign_of(float d)
 
 // ---- forward -------------------------------------------------------------------------------------
 // LEVEL 0: sums 0,1 (training loss).  LEVEL 1: all five sums (measure_linearity: std, error, count).
+#ifndef CT_FWD_KERNEL_ATTR
+#define CT_FWD_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 template <typename T, int INTERP, int STD, int PPT, int LEVEL, bool REL>
-__global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
+__global__ __launch_bounds__(kBlock) CT_FWD_KERNEL_ATTR void pair_fwd_kernel(const PairArgs a)
 {
     extern __shared__ __align__(16) char lds[];
     constexpr int kEntry = lut_entry_bytes(INTERP);
@@ -333,7 +336,10 @@ __global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const PairArgs a)
             const float2 *vi = val + bi[s], *vj = val + bj[s];
             const float *xi = aux + bi[s], *xj = aux + bj[s];
             // partial tiles: padding columns carry weight -inf and contribute nothing (their order is permuted when a.vec)
-#pragma unroll 8
+#ifndef CT_FWD_UNROLL
+#define CT_FWD_UNROLL 8
+#endif
+#pragma unroll CT_FWD_UNROLL
             for (int px = 0; px < ncol; ++px) {
                 const float2 A = vi[px], Bv = vj[px];
                 // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
@@ -406,6 +412,18 @@ constexpr int kBwdBlock = 1024;
 static int workgroups_per_channel(size_t lds_bytes, int block, uint32_t tiles)
 {
     return (int)std::min<uint32_t>(tiles, (uint32_t)resident_workgroups(lds_bytes, block));
+}
+
+// The same with the residency the runtime reports for the actual kernel (registers count too: the forward kernel's
+// LDS would admit four workgroups per CU where its VGPRs admit three, and a grid of four per CU then runs as one full
+// round plus a one-third-occupied second one).
+template <typename KernelT>
+static int workgroups_per_channel(KernelT kernel, size_t lds_bytes, int block, uint32_t tiles)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1)
+        return workgroups_per_channel(lds_bytes, block, tiles);
+    return (int)std::min<uint32_t>(tiles, (uint32_t)(compute_units() * per_cu));
 }
 
 // Entry of the pair-once backward's global partner table: 32 bytes, read with one s_load_dwordx8 (uniform index,
@@ -869,21 +887,22 @@ static int vec_ok(const PairArgs &a, int block, int max_passes)
     return aligned && (a.n_images + nstep - 1) / nstep <= max_passes ? 1 : 0;
 }
 
-template <typename T, int INTERP, int STD, int PPT>
-static int fwd_launch_level(const PairArgs &a, size_t lds, int grid, int level, hipStream_t s)
+template <typename T, int INTERP, int STD, int PPT, int LEVEL, bool REL>
+static int fwd_launch_one(const PairArgs &a, size_t lds, hipStream_t s)
 {
-    if (level == 0) {
-        if (a.use_relative)
-            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 0, true>), dim3(grid), dim3(kBlock), lds, s, a);
-        else
-            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 0, false>), dim3(grid), dim3(kBlock), lds, s, a);
-    } else {
-        if (a.use_relative)
-            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 1, true>), dim3(grid), dim3(kBlock), lds, s, a);
-        else
-            hipLaunchKernelGGL((pair_fwd_kernel<T, INTERP, STD, PPT, 1, false>), dim3(grid), dim3(kBlock), lds, s, a);
-    }
+    auto kernel = pair_fwd_kernel<T, INTERP, STD, PPT, LEVEL, REL>;
+    const uint32_t tiles = (a.plane_local + a.tp - 1) / a.tp;
+    const int grid = workgroups_per_channel(kernel, lds, kBlock, tiles) * a.channels;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int INTERP, int STD, int PPT>
+static int fwd_launch_level(const PairArgs &a, size_t lds, int level, hipStream_t s)
+{
+    if (level == 0)
+        return a.use_relative ? fwd_launch_one<T, INTERP, STD, PPT, 0, true>(a, lds, s) : fwd_launch_one<T, INTERP, STD, PPT, 0, false>(a, lds, s);
+    return a.use_relative ? fwd_launch_one<T, INTERP, STD, PPT, 1, true>(a, lds, s) : fwd_launch_one<T, INTERP, STD, PPT, 1, false>(a, lds, s);
 }
 
 template <typename T, int INTERP, int STD>
@@ -899,15 +918,12 @@ static int fwd_launch(PairArgs a, int level, hipStream_t s)
     a.row_pitch = tp + 1;
     a.vec = vec_ok<T>(a, kBlock, 8);
     const size_t lds = lut_bytes + (size_t)a.n_images * a.row_pitch * entry;
-    const uint32_t tiles = (a.plane_local + tp - 1) / tp;
-    const int per_chan = workgroups_per_channel(lds, kBlock, tiles);
-    const int grid = per_chan * a.channels;
     // pairs are walked in chunks of 4 * 256 per launch
     for (int begin = 0; begin < a.n_pairs; begin += 4 * kBlock) {
         a.pair_begin = begin;
         // always four pair slots per thread (slots past the end of the list are skipped): one instantiation instead of
         // three keeps the build time of this file in check
-        const int rc = fwd_launch_level<T, INTERP, STD, 4>(a, lds, grid, level, s);
+        const int rc = fwd_launch_level<T, INTERP, STD, 4>(a, lds, level, s);
         if (rc != CT_OK) return rc;
     }
     return CT_OK;
