@@ -30,6 +30,10 @@
 
 namespace ct {
 
+#ifndef CT_ABLATE_PAIR_PHASE
+#define CT_ABLATE_PAIR_PHASE 0  // 1 (tools/pairs_bench only): skip the pair loops, time staging + scatter + barriers alone
+#endif
+
 struct PairArgs {
     const void *stack;
     const float *std_stack;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(kBlock) CT_FWD_KERNEL_ATTR void pair_fwd_kernel(con
 #define CT_FWD_UNROLL 8
 #endif
 #pragma unroll CT_FWD_UNROLL
-            for (int px = 0; px < ncol; ++px) {
+            for (int px = 0; px < (CT_ABLATE_PAIR_PHASE ? 0 : ncol); ++px) {
                 const float2 A = vi[px], Bv = vj[px];
                 // expected = I_j * r, diff = I_i - expected (losses.py:41-43), compensated in float32
                 const float d1 = __builtin_fmaf(-Bv.x, rhi[s], A.x);
@@ -846,7 +850,7 @@ __global__ __launch_bounds__(kLaneBlock) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
             };
             float2 alt[kLaneCols];
-            for (int d = band; d >= 2; d -= 2) {
+            for (int d = CT_ABLATE_PAIR_PHASE ? 0 : band; d >= 2; d -= 2) {
                 step(d, oth, alt);
                 step(d - 1, alt, oth);
             }

@@ -430,3 +430,35 @@ def test_lane_backward_broken_promise_falls_back(dev):
     pairs.band = 16
     lane = ops.pair_residual_lut_grad(x, pairs, coef, **kw)
     assert not torch.equal(lane, good) and float((lane - good).norm() / good.norm()) < 1e-6
+
+
+def test_lane_backward_narrow_tiles(dev):
+    """A 512-entry LUT leaves room for 32-column tiles only beside the lane kernel's constants (two workgroups per CU):
+    the narrow-tile route of the lane kernel against the generic kernel and the eager oracle."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.training import linearity_loss
+    from oracle import eager_torch as oe
+    gen = torch.Generator().manual_seed(77)
+    n, c, h, w = 64, 3, 9, 52
+    t = torch.tensor([0.001 * 2.0 ** (k * 0.125) for k in range(n)], dtype=torch.float64)
+    e = torch.rand((c, h, w), generator=gen, dtype=torch.float64) * (2.0 / float(torch.sqrt(t[0] * t[-1])))
+    x = ((e.unsqueeze(0) * t.view(-1, 1, 1, 1)).clamp(0, 1) ** (1 / 2.2)).float()
+    x = (x + 0.01 * torch.randn(x.shape, generator=gen)).clamp(0, 1)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n, dev)
+    lut0 = torch.stack([torch.linspace(0, 1, 512) ** p for p in (1.9, 2.2, 2.5)])
+    coef = (torch.rand((pairs.n_pairs, c), generator=gen, dtype=torch.float64) * 1e-4).to(dev)
+    kw = dict(lut=lut0.to(dev), interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False)
+    g_lane = ops.pair_residual_lut_grad(x.to(dev), pairs, coef, **kw)
+    g_generic = ops.pair_residual_lut_grad(x.to(dev), pairs, coef, lane_kernel=False, **kw)
+    assert not torch.equal(g_lane, g_generic)  # two different kernels ...
+    assert_parity(g_lane.cpu().numpy(), g_generic.cpu().numpy(), norm_tol=5e-7, elem_tol=1e-5, what="narrow tiles: lane = generic")
+    lo = lut0.clone().requires_grad_(True)
+    _, lin_o, _ = oe.training_loss(x, None, t, lo, "linear", 0.25, 1 / 255, 254 / 255, True, False)
+    grad_o = torch.autograd.grad(lin_o.sum(), lo)[0]
+    lut = lut0.to(dev).requires_grad_(True)
+    lin, _ = linearity_loss(lut, x.to(dev), pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
+                            use_unc_weight=False)
+    grad = torch.autograd.grad(lin.sum(), lut)[0]
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=2e-5, what="narrow tiles: LUT gradient vs oracle")
