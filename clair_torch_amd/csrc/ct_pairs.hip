@@ -337,7 +337,11 @@ __global__ __launch_bounds__(kBlock) CT_FWD_KERNEL_ATTR void pair_fwd_kernel(con
             float f[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) f[k] = 0.0f;
+#ifdef CT_ABLATE_FWD_ONE_READ  // tools/pairs_bench only: both operands from one LDS read (wrong sums, timing only)
+            const float2 *vi = val + bi[s], *vj = vi;
+#else
             const float2 *vi = val + bi[s], *vj = val + bj[s];
+#endif
             const float *xi = aux + bi[s], *xj = aux + bj[s];
             // partial tiles: padding columns carry weight -inf and contribute nothing (their order is permuted when a.vec)
 #ifndef CT_FWD_UNROLL
