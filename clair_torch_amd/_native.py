@@ -22,7 +22,8 @@ ABI_VERSION = 2
 EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd",
            "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_pair_residual_bwd_workspace", "ct_flatfield_sums",
            "ct_flatfield_apply", "ct_video_stats_batch", "ct_dark_field_blur", "ct_hdr_merge_kernel_name",
-           "ct_merge_set_retry_counter", "ct_norm_constants", "ct_index_constants", "ct_pivot_index_constants")
+           "ct_merge_set_retry_counter", "ct_norm_constants", "ct_index_constants", "ct_pivot_index_constants",
+           "ct_pivot_floor_constants")
 
 
 class Geometry(ctypes.Structure):

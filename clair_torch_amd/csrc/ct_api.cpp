@@ -142,3 +142,42 @@ extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *
     *step = cached_step;
     return cached_rc;
 }
+
+// The typed-load path of merge_pivot_kernel receives the codes as floats and forms the interval by ONE FMA that rounds
+// toward minus infinity: as_uint(fma_rtn(u, r, 1.5 * 2^23)) - 0x4B400000 with r = 1 / step rounded up.  Emulated here in
+// exact integer arithmetic (u * r is a multiple of 2^e with r = M 2^e, its floor is a 64-bit shift; adding it to the
+// magic number and rounding down at ulp 1 is exact) and compared with the reference's float32 interval
+// floor(fl(fl(u / max_code) * (L-1))) (clair_torch/models/base.py:166-168) for EVERY code; cached per (max_code, L).
+extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp_step)
+{
+    static std::mutex mu;
+    static float cached_max = 0.0f, cached_rcp = 0.0f;
+    static int cached_L = 0, cached_rc = CT_ERR_UNSUPPORTED;
+    uint32_t mul = 0;
+    float step = 0.0f;
+    const int rc0 = ct_pivot_index_constants(max_code, n_points, &mul, &step);  // step integral, integer form verified
+    if (rc0 != CT_OK) return rc0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached_max != max_code || cached_L != n_points) {
+        const int maxc = (int)max_code, top = n_points - 1;
+        float r = (float)(1.0 / (double)step);
+        if ((double)r < 1.0 / (double)step) r = nextafterf(r, 2.0f);
+        int e = 0;
+        const double m = frexp((double)r, &e);         // r = m 2^e, m in [0.5, 1)
+        const uint64_t M = (uint64_t)ldexp(m, 24);      // 24-bit integer significand (exact: r is a float)
+        const int shift = 24 - e;                       // r = M 2^-shift (r <= 1, so shift >= 23)
+        int rc = (shift >= 0 && shift < 63) ? CT_OK : CT_ERR_UNSUPPORTED;
+        for (int u = 0; rc == CT_OK && u <= maxc; ++u) {
+            volatile float x = (float)u / max_code;
+            volatile float s_ref = x * (float)top;
+            const uint64_t got = ((uint64_t)u * M) >> shift;
+            if (got != (uint64_t)floorf(s_ref) || got > (uint64_t)top) rc = CT_ERR_UNSUPPORTED;
+        }
+        cached_max = max_code;
+        cached_L = n_points;
+        cached_rcp = r;
+        cached_rc = rc;
+    }
+    *rcp_step = cached_rcp;
+    return cached_rc;
+}

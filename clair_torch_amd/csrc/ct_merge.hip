@@ -455,6 +455,82 @@ __device__ __forceinline__ P load_buffer(uint64_t base, uint32_t offset)
     return out;
 }
 
+// Typed buffer loads (round 2): with DATA_FORMAT 16_16_16_16 / 8_8_8_8 (16 / 8 for single codes) and NUM_FORMAT USCALED
+// in the descriptor, buffer_load_format_xyzw delivers (float)code for the four packed codes -- the conversion happens
+// in the texture-data path on the way to the registers, which is idle here, instead of one half-rate
+// v_cvt_f32_u32_sdwa per sample on the VALU, which is the unit this kernel is bound by.  Exact for every code
+// (tools/typed_load_probe.hip checks all 65 536 in every component on the device).
+#ifndef CT_PIVOT_TYPED_LOAD
+#define CT_PIVOT_TYPED_LOAD 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ f32x4_t raw_buffer_load_format_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
+__device__ float raw_buffer_load_format_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.f32");
+// word 3 of the gfx9 buffer descriptor: DST_SEL_{X,Y,Z,W} = R,G,B,A (4,5,6,7) | NUM_FORMAT << 12 (2 = USCALED) |
+// DATA_FORMAT << 15 (1 = 8, 2 = 16, 10 = 8_8_8_8, 12 = 16_16_16_16)
+template <typename T, int V>
+constexpr uint32_t uscaled_format_word()
+{
+    static_assert((V == 1 || V == 4) && (sizeof(T) == 1 || sizeof(T) == 2), "typed loads: 1 or 4 codes of 8 or 16 bits");
+    constexpr uint32_t sel = V == 4 ? (4u | (5u << 3) | (6u << 6) | (7u << 9)) : 4u;
+    constexpr uint32_t dfmt = V == 4 ? (sizeof(T) == 2 ? 12u : 10u) : (sizeof(T) == 2 ? 2u : 1u);
+    return sel | (2u << 12) | (dfmt << 15);
+}
+template <typename T, int V>
+__device__ __forceinline__ Packet<float, V> load_codes_as_float(uint64_t base, uint32_t offset)
+{
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, 0xffffffff, (int)uscaled_format_word<T, V>());
+    Packet<float, V> out;
+    if constexpr (V == 4) {
+        const f32x4_t v = raw_buffer_load_format_v4f32(rsrc, (int)offset, 0, CT_STACK_LOAD_AUX);
+        __builtin_memcpy(&out, &v, sizeof(out));
+    } else {
+        out.v[0] = raw_buffer_load_format_f32(rsrc, (int)offset, 0, CT_STACK_LOAD_AUX);
+    }
+    return out;
+}
+
+// LUT interval of V codes held as floats: floor(px / step) = mantissa of fma(px, r, 1.5 * 2^23) when that one FMA rounds
+// toward minus infinity (r = 1 / step rounded up, so exact multiples of the step do not fall below their interval; the
+// error of px * r stays below 1.6e-5 < 1 / step).  FP_ROUND of the MODE register is switched for exactly these V
+// instructions -- one asm block, so the compiler cannot move any other arithmetic into it; the scalar unit is idle.
+// The result keeps the magic number's bits: as_uint(t) = 0x4B400000 + interval; the callers fold that constant into
+// the row offset they add anyway.  Host-verified for every code against the reference's float32 index
+// (ct_pivot_index_constants) and on the device by tools/typed_load_probe.hip.
+constexpr float kFloorMagic = 12582912.0f;        // 1.5 * 2^23: ulp 1
+constexpr uint32_t kFloorMagicBits = 0x4B400000u;
+template <int V>
+__device__ __forceinline__ void floor_index_bits(const float (&px)[V], float r, float magic, float (&t)[V])
+{
+    if constexpr (V == 4) {
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
+                     "v_fma_f32 %0, %4, %8, %9\n\t"
+                     "v_fma_f32 %1, %5, %8, %9\n\t"
+                     "v_fma_f32 %2, %6, %8, %9\n\t"
+                     "v_fma_f32 %3, %7, %8, %9\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                     : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(r), "v"(magic));
+    } else {
+        static_assert(V == 1, "1 or 4 codes");
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
+                     "v_fma_f32 %0, %1, %2, %3\n\t"
+                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                     : "=&v"(t[0])
+                     : "v"(px[0]), "v"(r), "v"(magic));
+    }
+}
+
+// LDS byte address of table entry `interval` of the row at byte offset `row`: (bits(t) << 3) + (row - (0x4B400000 << 3))
+// mod 2^32, one v_lshl_add_u32; the row constant is formed once per tile.  (Tried and rejected: the same address by one
+// full-rate FMA against the inline integer constant 8 read as the denormal 8 * 2^-149 -- exact, but denormal operands
+// take a slow path: 0.879 against 0.856 ms on C2, profiles/r02_typed_load_ab.log.)
+__device__ __forceinline__ uint32_t lds_row_constant(int row_bytes) { return (uint32_t)row_bytes - (kFloorMagicBits << 3); }
+__device__ __forceinline__ uint32_t lds_entry_address(float t, uint32_t row_constant) { return (__float_as_uint(t) << 3) + row_constant; }
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>)
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -470,6 +546,7 @@ struct PivotArgs {
     float step;          // max_code / (L-1), an integer
     uint32_t n_tiles;    // tiles of kBlock * V elements
     int32_t probe;       // exposure whose sample seeds the pivot of a first batch
+    float index_rcp;     // 1 / step rounded up: floor(code / step) by one round-down FMA (typed-load path)
     unsigned long long *retry_count;  // diagnostics: wavefronts that ran the fallback pass (may be NULL)
 };
 
@@ -480,10 +557,12 @@ constexpr int kPivotDepth = CT_PIVOT_DEPTH;  // exposures in flight per thread
 constexpr float kPivotCondLimit = 8.0f;
 constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which the table keeps {g[i], S}: error bound 2^-25 * 64 = 2e-6  // sum |terms| / result above which a wavefront repeats the batch about the mean
 
-// The first-batch kernels (no state carried through the loop) fit 64 VGPRs without spilling: ask for 8 wavefronts per
-// SIMD (measured up to 10 % faster than the 6 the default allocation of 76 gives; the state-carrying ones keep 6).
+// The first-batch kernels (no state carried through the loop): 7 wavefronts per SIMD (72 VGPRs).  With the codes held as
+// four floats per packet instead of two packed dwords the 64-VGPR build spills 19 registers (1.24 ms); 7 and 6
+// wavefronts measure the same within 1 % (0.856 / 0.865 ms sustained, profiles/r02_typed_load_ab.log).  Raw-code
+// builds (CT_PIVOT_TYPED_LOAD=0) fit 64.  The state-carrying kernels keep the default allocation.
 #ifndef CT_PIVOT_KERNEL_ATTR
-#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? 8 : 4, 8)))
+#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? 7 : 8) : 4, 8)))
 #endif
 template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST>
 __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kernel(const MergeArgs a, const PivotArgs x)
@@ -494,6 +573,8 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     constexpr bool kLut = INTERP == CT_INTERP_LINEAR;
     constexpr bool kHasStd = STD != CT_STD_NONE;
     constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
+    constexpr bool kTyped = CT_PIVOT_TYPED_LOAD;  // codes arrive as floats from typed buffer loads
+    using CodePk = std::conditional_t<kTyped, Packet<float, V>, Packet<T, V>>;
     const int C = a.channels, L = a.n_points, B = a.batch;
     const int lut_bytes = kLut ? C * L * 8 : 0;
     float2 *expo = reinterpret_cast<float2 *>(lds + lut_bytes);  // per exposure {1 / t_n, chain factor of the y' term}
@@ -547,7 +628,10 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     if constexpr (STD == CT_STD_CONSTANT) fsf *= a.std_value;
     if constexpr (STD == CT_STD_MULTIPLIER) fsf *= a.std_value * a.inv_max_code;
     const float sv2 = fsf * fsf;
-    const uint32_t index_mul = x.index_mul & 0xffffffu;
+    [[maybe_unused]] const uint32_t index_mul = x.index_mul & 0xffffffu;
+    [[maybe_unused]] const float index_rcp = x.index_rcp;
+    [[maybe_unused]] float floor_magic = kFloorMagic;
+    asm volatile("" : "+v"(floor_magic));  // one VGPR for the whole kernel (a VOP3 FMA cannot carry a literal)
 
     for (uint32_t tile = blockIdx.x; tile < x.n_tiles; tile += gridDim.x) {
         const uint32_t vec = tile * (uint32_t)kBlock + threadIdx.x;
@@ -589,6 +673,11 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 #pragma unroll
             for (int e = 0; e < V; ++e) row_off[e] = 0;
         }
+        [[maybe_unused]] uint32_t rowc[V];  // typed path: the row offset as the addend of lds_entry_address
+        if constexpr (kTyped && kLut) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) rowc[e] = lds_row_constant(row_off[e]);
+        }
 
         // loads are addressed as (wave-uniform exposure base) + (32-bit per-thread byte offset): no 64-bit VALU address math
         const uint32_t voff = q0 * (uint32_t)sizeof(T), svoff = q0 * 4u;
@@ -597,7 +686,23 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         constexpr int VS = FIRST ? 1 : V;  // state registers exist only when there is state
         float p[V], WA[VS], varA[VS];
         double meanA[VS];
-        if constexpr (FIRST) {
+        if constexpr (FIRST && kTyped) {
+            const Packet<float, V> pk = load_codes_as_float<T, V>(
+                reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)x.probe * a.image_stride * (int64_t)sizeof(T)), voff);
+            const float itp = expo[x.probe].x;
+            float tf[V];
+            if constexpr (kLut) floor_index_bits<V>(pk.v, index_rcp, floor_magic, tf);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float px = pk.v[e];
+                float lin = px * a.inv_max_code;
+                if constexpr (kLut) {
+                    const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address(tf[e], rowc[e]));
+                    lin = __builtin_fmaf(g.y, rough ? __builtin_fmaf(tf[e] - floor_magic, -x.step, px) : px, g.x);
+                }
+                p[e] = lin * itp;
+            }
+        } else if constexpr (FIRST) {
             const Packet<T, V> pk = load_buffer<Packet<T, V>>(
                 reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)x.probe * a.image_stride * (int64_t)sizeof(T)), voff);
             const float itp = expo[x.probe].x;
@@ -633,14 +738,28 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             auto run_batch = [&](auto rough_c) {
             constexpr bool kRough = decltype(rough_c)::value;  // see the staging: exact but slower interval arithmetic
             // one exposure of this thread's V elements
-            auto reduce = [&](const Packet<T, V> &pk, const Packet<float, V> &sp, int n) {
-                const float2 ex = expo[n];
+            auto reduce = [&](const CodePk &pk, const Packet<float, V> &sp, uint32_t expo_adr) {
+                const float2 ex = *reinterpret_cast<const float2 *>(lds + expo_adr);  // {1 / t_n, chain factor} of this exposure
                 const float it = ex.x, cqn = ex.y;
                 float pxv[V], ga[V], gs[V];
                 [[maybe_unused]] float pxl[V];
                 [[maybe_unused]] float dkv[V], wv[V];
+                [[maybe_unused]] float tf[V];
+                if constexpr (kTyped) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) pxv[e] = pk.v[e];
+                    if constexpr (kLut) floor_index_bits<V>(pxv, index_rcp, floor_magic, tf);
+                }
                 static_for<V>([&](auto ec) {  // stage A: the V table gathers and the V transcendentals, each issued together
                     constexpr int e = decltype(ec)::value;
+                    if constexpr (kTyped) {
+                        if constexpr (kLut) {
+                            const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address(tf[e], rowc[e]));
+                            ga[e] = g.x;
+                            gs[e] = g.y;
+                            if constexpr (kRough) pxl[e] = __builtin_fmaf(tf[e] - floor_magic, -x.step, pxv[e]);  // code - i * step, exact
+                        }
+                    } else {
                     pxv[e] = code_to_float<T, V, e>(pk);
                     if constexpr (kLut) {
                         const uint32_t i0 = code_to_interval<T, V, e>(pk, index_mul);
@@ -648,6 +767,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                         ga[e] = g.x;
                         gs[e] = g.y;
                         if constexpr (kRough) pxl[e] = __builtin_fmaf((float)i0, -x.step, pxv[e]);  // code - i * step, exact
+                    }
                     }
                     if constexpr (kGauss) {
                         dkv[e] = __builtin_fmaf(pxv[e], dk_mul, dk_add);
@@ -695,14 +815,17 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             // Software pipeline: kDepth exposures in flight per thread, kDepth + 1 per trip through rotating registers
             // (the slot freed by one step is re-filled by the next), so that no packet is ever copied -- a copy would
             // make the wavefront wait for the load it has just issued.
-            auto fetch = [&](int n, Packet<T, V> &pk, Packet<float, V> &sp) {
+            auto fetch = [&](int n, CodePk &pk, Packet<float, V> &sp) {
                 const int nn = n < B ? n : B - 1;  // past the end: re-load the last exposure (cache hit, unused)
                 // Buffer loads: (scalar descriptor rebased to the exposure) + (32-bit per-thread byte offset) -- no vector
                 // address arithmetic.  The base is laundered through an empty asm so LLVM cannot prove the prefetched
                 // packet equal to a fresh load at its use (it would re-load there and drop the prefetch).
                 uint64_t base = reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)nn * a.image_stride * (int64_t)sizeof(T));
                 asm volatile("" : "+s"(base));
-                pk = load_buffer<Packet<T, V>>(base, voff);
+                if constexpr (kTyped)
+                    pk = load_codes_as_float<T, V>(base, voff);
+                else
+                    pk = load_buffer<Packet<T, V>>(base, voff);
                 if constexpr (STD == CT_STD_EXPLICIT) {
                     uint64_t sbase = reinterpret_cast<uint64_t>(a.std_stack) + (uint64_t)((int64_t)nn * a.image_stride * 4);
                     asm volatile("" : "+s"(sbase));
@@ -710,18 +833,20 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 }
             };
             constexpr int kRing = kPivotDepth + 1;
-            Packet<T, V> ring[kRing];
+            CodePk ring[kRing];
             Packet<float, V> sring[STD == CT_STD_EXPLICIT ? kRing : 1];
             static_for<kPivotDepth>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 fetch(j, ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0]);
             });
+            uint32_t expo_adr = (uint32_t)lut_bytes;  // LDS byte address of this trip's per-exposure constants
             for (int n = 0; n < B; n += kRing) {
                 static_for<kRing>([&](auto jc) {
                     constexpr int j = decltype(jc)::value, slot = (j + kPivotDepth) % kRing;
                     fetch(n + j + kPivotDepth, ring[slot], sring[STD == CT_STD_EXPLICIT ? slot : 0]);
-                    if (j == 0 || n + j < B) reduce(ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0], n + j);
+                    if (j == 0 || n + j < B) reduce(ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0], expo_adr + 8u * j);
                 });
+                expo_adr += 8u * kRing;
             }
             };
             if (rough)
@@ -1003,6 +1128,8 @@ extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
 extern "C" int ct_index_constants(float max_code, int n_points, float *hi, float *lo);
 // Host check that (code * index_mul) >> 32 (uint16) / the code itself (uint8) is the reference's LUT interval for every code.
 extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
+// Host check that the round-down FMA on the code held as a float gives the same interval (typed-load path).
+extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp_step);
 
 // Diagnostics (not part of the data path): device counter that merge_pivot_kernel bumps once per wavefront that ran
 // its fallback pass.  NULL (the default) disables counting.  Process-global; set it only around a measurement.
@@ -1019,10 +1146,12 @@ static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_poin
     if (interp != CT_INTERP_LINEAR && interp != CT_INTERP_NONE) return false;
     px->step = 1.0f;
     px->index_mul = 0;
+    px->index_rcp = 1.0f;
     if (interp == CT_INTERP_LINEAR) {
         if (ct_pivot_index_constants(max_code, n_points, &px->index_mul, &px->step) != CT_OK) return false;
         if (dtype == CT_DTYPE_U8 && px->step != 1.0f) return false;   // uint8 kernel: the code is the index
         if (dtype == CT_DTYPE_U16 && px->index_mul == 0) return false;
+        if (CT_PIVOT_TYPED_LOAD && ct_pivot_floor_constants(max_code, n_points, &px->index_rcp) != CT_OK) return false;
     }
     return true;
 }
@@ -1035,7 +1164,7 @@ extern "C" const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, i
     if (pivot_eligible(dtype, max_code, interp, interp == CT_INTERP_NONE ? 2 : n_points, flags, &px))
         return (flags & CT_MERGE_FIRST_BATCH)
                    ? "ct::merge_pivot_kernel (float32 moments about a per-pixel pivot, persistent workgroups, 4 codes per "
-                     "thread, 8 wavefronts per SIMD, first batch)"
+                     "thread through typed buffer loads, 7 wavefronts per SIMD, first batch)"
                    : "ct::merge_pivot_kernel (float32 moments about the running mean, persistent workgroups, 4 codes per "
                      "thread, streaming state)";
     return dtype == CT_DTYPE_F32 ? "ct::merge_kernel (float64 moments, float32 pixels, 4 per thread)"

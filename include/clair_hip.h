@@ -126,10 +126,13 @@ int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int
  *   ct_pivot_index_constants floor(u (L-1) / max_code) == (u * index_mul) >> 32 (or == u when *index_mul == 0) for every
  *                            code, with step = max_code / (L-1) an integer (what ct::merge_pivot_kernel addresses its
  *                            table with)
+ *   ct_pivot_floor_constants the same interval from the code held as a float (typed buffer loads): mantissa of
+ *                            fma(u, *rcp_step, 1.5 * 2^23) rounded toward minus infinity, for every code
  */
 int ct_norm_constants(float max_code, float *hi, float *lo);
 int ct_index_constants(float max_code, int n_points, float *hi, float *lo);
 int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
+int ct_pivot_floor_constants(float max_code, int n_points, float *rcp_step);
 
 /* Diagnostics: a static string naming the kernel ct_hdr_merge_batch dispatches for these arguments. */
 const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, int32_t interp, int32_t n_points, uint32_t flags);

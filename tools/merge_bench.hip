@@ -136,6 +136,7 @@ int main(int argc, char **argv)
     a.flags = CT_MERGE_FIRST_BATCH | CT_MERGE_FINALIZE;
 
     if (ct_pivot_index_constants(65535.0f, 256, &g_px.index_mul, &g_px.step) != CT_OK) { printf("pivot index refused\n"); return 1; }
+    if (ct_pivot_floor_constants(65535.0f, 256, &g_px.index_rcp) != CT_OK) { printf("pivot floor constants refused\n"); return 1; }
     g_px.probe = N / 2;
     unsigned long long *retries; CK(hipMalloc(&retries, 8)); CK(hipMemset(retries, 0, 8));
     g_px.retry_count = retries;
