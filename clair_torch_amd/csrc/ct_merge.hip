@@ -493,43 +493,7 @@ __device__ __forceinline__ Packet<float, V> load_codes_as_float(uint64_t base, u
     return out;
 }
 
-// LUT interval of V codes held as floats: floor(px / step) = mantissa of fma(px, r, 1.5 * 2^23) when that one FMA rounds
-// toward minus infinity (r = 1 / step rounded up, so exact multiples of the step do not fall below their interval; the
-// error of px * r stays below 1.6e-5 < 1 / step).  FP_ROUND of the MODE register is switched for exactly these V
-// instructions -- one asm block, so the compiler cannot move any other arithmetic into it; the scalar unit is idle.
-// The result keeps the magic number's bits: as_uint(t) = 0x4B400000 + interval; the callers fold that constant into
-// the row offset they add anyway.  Host-verified for every code against the reference's float32 index
-// (ct_pivot_index_constants) and on the device by tools/typed_load_probe.hip.
-constexpr float kFloorMagic = 12582912.0f;        // 1.5 * 2^23: ulp 1
-constexpr uint32_t kFloorMagicBits = 0x4B400000u;
-template <int V>
-__device__ __forceinline__ void floor_index_bits(const float (&px)[V], float r, float magic, float (&t)[V])
-{
-    if constexpr (V == 4) {
-        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
-                     "v_fma_f32 %0, %4, %8, %9\n\t"
-                     "v_fma_f32 %1, %5, %8, %9\n\t"
-                     "v_fma_f32 %2, %6, %8, %9\n\t"
-                     "v_fma_f32 %3, %7, %8, %9\n\t"
-                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
-                     : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(r), "v"(magic));
-    } else {
-        static_assert(V == 1, "1 or 4 codes");
-        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
-                     "v_fma_f32 %0, %1, %2, %3\n\t"
-                     "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                     : "=&v"(t[0])
-                     : "v"(px[0]), "v"(r), "v"(magic));
-    }
-}
-
-// LDS byte address of table entry `interval` of the row at byte offset `row`: (bits(t) << 3) + (row - (0x4B400000 << 3))
-// mod 2^32, one v_lshl_add_u32; the row constant is formed once per tile.  (Tried and rejected: the same address by one
-// full-rate FMA against the inline integer constant 8 read as the denormal 8 * 2^-149 -- exact, but denormal operands
-// take a slow path: 0.879 against 0.856 ms on C2, profiles/r02_typed_load_ab.log.)
-__device__ __forceinline__ uint32_t lds_row_constant(int row_bytes) { return (uint32_t)row_bytes - (kFloorMagicBits << 3); }
-__device__ __forceinline__ uint32_t lds_entry_address(float t, uint32_t row_constant) { return (__float_as_uint(t) << 3) + row_constant; }
+// (floor_index_bits, lds_row_constant, lds_entry_address: ct_device.hpp -- shared with the training kernels)
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>)
 template <int N, int I = 0, typename F>

@@ -65,6 +65,14 @@ struct PairArgs {
     NormConst norm;
     float lower, upper, neg_scale_log2e, std_value;
     int32_t use_relative, use_unc_weight;
+    // Code-domain staging (integer stacks at full range, LINEAR, no uncertainties, LUT step a whole number of codes;
+    // fill_code_domain): everything a sample needs is formed from the raw code as a float -- no normalisation, no
+    // float LUT coordinate, no floor / float -> int chain.
+    int32_t code_domain;
+    float code_rcp;        // 1 / step rounded up: interval = floor(code / step) by one round-down FMA (ct_device.hpp)
+    float code_step, code_inv_step;
+    float code_lo, code_hi;          // smallest / largest code whose normalised value lies in [lower, upper]
+    float code_dk_mul, code_dk_add;  // Gaussian weight = exp2(-dk^2), dk = code * mul + add
 };
 
 template <typename T>
@@ -96,6 +104,37 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
     // samples are walked in batches of kBatch with all of a batch's HBM loads issued before the first is used
     constexpr int kBatch = 4;
     const T *src = static_cast<const T *>(a.stack) + ql;
+    if constexpr (sizeof(T) != 4 && INTERP == CT_INTERP_LINEAR && STD == CT_STD_NONE) {
+        if (a.code_domain) {
+            const uint32_t rowc = lds_row_constant((inb ? lut_row<INTERP>(qg, c, a.channels) : 0) * L * kEntry);
+            float magic = kFloorMagic;
+            asm volatile("" : "+v"(magic));
+            for (int nb = n0; nb < N; nb += kBatch * nstep) {
+                T raw[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const int n = nb + k * nstep;
+                    raw[k] = (inb && n < N) ? src[(int64_t)n * a.image_stride] : T(0);
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const int n = nb + k * nstep;
+                    if (n >= N) break;
+                    float2 v = make_float2(0.0f, -INFINITY);
+                    float ax = 0.0f;
+                    if (inb) {
+                        const float pxv[1] = {(float)raw[k]};
+                        float tf[1];
+                        floor_index_bits<1>(pxv, a.code_rcp, magic, tf);
+                        v = code_domain_sample<WANT_COORD>(a, lut_lds, rowc, tf[0], magic, pxv[0], ax);
+                    }
+                    val[n * a.row_pitch + px] = v;
+                    if constexpr (WANT_COORD) aux[n * a.row_pitch + px] = ax;
+                }
+            }
+            return;
+        }
+    }
     for (int nb = n0; nb < N; nb += kBatch * nstep) {
         T raw[kBatch];
         float sraw[kBatch];
@@ -155,6 +194,42 @@ template <> struct RawVec<float> { using type = float4; };
 __device__ __forceinline__ uint8_t raw_elem(uint32_t v, int e) { return (uint8_t)(v >> (8 * e)); }
 __device__ __forceinline__ uint16_t raw_elem(uint2 v, int e) { return (uint16_t)((e < 2 ? v.x : v.y) >> (16 * (e & 1))); }
 __device__ __forceinline__ float raw_elem(float4 v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// element e of a packed raw vector as a float: one conversion straight from the packed dword (no unpacking)
+__device__ __forceinline__ float raw_code_as_float(uint32_t v, int e) { return (float)((v >> (8 * e)) & 0xffu); }  // v_cvt_f32_ubyteN
+__device__ __forceinline__ float raw_code_as_float(uint2 v, int e)
+{
+    const uint32_t dw = e < 2 ? v.x : v.y;
+    float r;
+    if (e & 1)
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(dw));
+    else
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(dw));
+    return r;
+}
+__device__ __forceinline__ float raw_code_as_float(float4, int) { return 0.0f; }  // never used: float stacks are not code-domain
+
+// One sample of the code-domain staging: t = 1.5 * 2^23 + interval (floor_index_bits), px = the code as a float.
+//   f = g[i] + slope * (px - i * step)   offset exact, ONE rounding in the FMA: closer to the exact interpolant than the
+//                                        reference's own float32 order g0 * (1 - w) + g1 * w (three roundings), and equal
+//                                        to it bit for bit when step == 1
+//   gauss = exp2(-(px * mul + add)^2), -inf outside [code_lo, code_hi] (the reference's mask on the normalised value,
+//           translated to codes on the host with the reference's own float32 division)
+//   coordinate (backward) = i + (px - i * step) / step
+template <bool WANT_COORD>
+__device__ __forceinline__ float2 code_domain_sample(const PairArgs &a, const char *lut_lds, uint32_t row_constant, float t,
+                                                     float magic, float px, float &coord)
+{
+    const float2 g = *reinterpret_cast<const float2 *>(lut_lds + lds_entry_address(t, row_constant));
+    const float i0f = t - magic;                                // exact
+    const float off = __builtin_fmaf(i0f, -a.code_step, px);    // exact: an integer below step
+    const float lin = __builtin_fmaf(g.y, off, g.x);
+    const float dk = __builtin_fmaf(px, a.code_dk_mul, a.code_dk_add);
+    const float gw = __builtin_amdgcn_exp2f(-dk * dk);
+    const bool valid = __builtin_amdgcn_fmed3f(px, a.code_lo, a.code_hi) == px;
+    if constexpr (WANT_COORD) coord = __builtin_fmaf(off, a.code_inv_step, i0f);
+    return make_float2(lin, valid ? gw : -INFINITY);
+}
 
 __device__ __forceinline__ int pixel_of_column(const PairArgs &a, int col)
 {
@@ -219,6 +294,34 @@ struct VecStager {
                 if constexpr (INTERP != CT_INTERP_LOOKUP) r = r + 1 == a.channels ? 0 : r + 1;
             }
         }
+        if constexpr (sizeof(T) != 4 && INTERP == CT_INTERP_LINEAR && STD == CT_STD_NONE) {
+            if (a.code_domain) {
+                uint32_t rowc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rowc[e] = lds_row_constant(row_off[e]);
+                float magic = kFloorMagic;
+                asm volatile("" : "+v"(magic));
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const int n = n0 + k * nstep;
+                    if (n >= N) break;
+                    float pxv[4], tf[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pxv[e] = raw_code_as_float(raw[k], e);
+                    floor_index_bits<4>(pxv, a.code_rcp, magic, tf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float2 v = make_float2(0.0f, -INFINITY);
+                        float ax = 0.0f;
+                        if (inb) v = code_domain_sample<WANT_COORD>(a, lut_lds, rowc[e], tf[e], magic, pxv[e], ax);
+                        const int at = n * a.row_pitch + e * G + pg;
+                        val[at] = v;
+                        if constexpr (WANT_COORD) aux[at] = ax;
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
             const int n = n0 + k * nstep;
@@ -279,7 +382,10 @@ __global__ __launch_bounds__(kBlock) CT_FWD_KERNEL_ATTR void pair_fwd_kernel(con
     const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : ((C * L * kEntry + 15) & ~15);
     float2 *val = reinterpret_cast<float2 *>(lds + lut_bytes);
     float *aux = reinterpret_cast<float *>(val + (size_t)N * a.row_pitch);
-    stage_lut<INTERP>(lds, a.lut, C, L);
+    if (INTERP == CT_INTERP_LINEAR && a.code_domain)
+        stage_lut_slope(lds, a.lut, C, L, a.code_step);
+    else
+        stage_lut<INTERP>(lds, a.lut, C, L);
 
     // my pairs
     int bi[PPT], bj[PPT];
@@ -645,7 +751,10 @@ __global__ __launch_bounds__(kBwdBlock) void pair_bwd_once_kernel(const PairArgs
     ConstWords ent = (ConstWords)(uintptr_t)(static_cast<const OnceEntry *>(a.table_g) + (size_t)c * a.n_pairs);
     if (first[N + 1 + c] == 0) return;  // no upstream gradient for this channel (uniform: the whole workgroup leaves)
     if (first[N + 1 + C + c] != 0) return;  // the lane <-> sample kernel of this launch sequence handles the channel
-    stage_lut<INTERP>(lds, a.lut, C, L);
+    if (INTERP == CT_INTERP_LINEAR && a.code_domain)
+        stage_lut_slope(lds, a.lut, C, L, a.code_step);
+    else
+        stage_lut<INTERP>(lds, a.lut, C, L);
     for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int nwaves = kBwdBlock >> 6;
@@ -782,7 +891,10 @@ __global__ __launch_bounds__(kLaneBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     typedef const int32_t __attribute__((address_space(4))) *ConstInts;
     ConstInts first = (ConstInts)(uintptr_t)a.first_g;
     if (first[N + 1 + c] == 0 || first[N + 1 + C + c] == 0) return;  // no gradient / the generic kernel has the channel
-    stage_lut<INTERP>(lds, a.lut, C, L);
+    if (INTERP == CT_INTERP_LINEAR && a.code_domain)
+        stage_lut_slope(lds, a.lut, C, L, a.code_step);
+    else
+        stage_lut<INTERP>(lds, a.lut, C, L);
     for (int k = threadIdx.x; k < C * L; k += blockDim.x) hist64[k] = 0.0;
     {
         const float4 *src = static_cast<const float4 *>(a.lane_table_g) + (size_t)c * band * 64;
@@ -1137,6 +1249,43 @@ static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, con
 }  // namespace ct
 
 extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
+extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
+extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp_step);
+
+namespace ct {
+// Code-domain staging is taken for integer stacks at the type's full range with a LINEAR curve whose step is a whole
+// number of codes (host-verified for every code: ct_pivot_floor_constants) and no uncertainties.  The reference's validity
+// mask lower <= fl(u / max) <= upper (general_functions.py:302) becomes a code interval by bisection with the same float32
+// division (monotone in u); an empty interval keeps the generic staging.
+static void fill_code_domain(PairArgs &a, int32_t dtype, float max_code, int interp, int std_mode, float weight_scale)
+{
+    a.code_domain = 0;
+    if (interp != CT_INTERP_LINEAR || std_mode != CT_STD_NONE) return;
+    if (max_code != (dtype == CT_DTYPE_U8 ? 255.0f : 65535.0f)) return;
+    uint32_t mul = 0;
+    float step = 0.0f, rcp = 0.0f;
+    if (ct_pivot_index_constants(max_code, a.n_points, &mul, &step) != CT_OK) return;
+    if (ct_pivot_floor_constants(max_code, a.n_points, &rcp) != CT_OK) return;
+    const int maxc = (int)max_code;
+    auto norm = [&](int u) { const float uf = (float)u; return fmaf(uf, a.norm.hi, uf * a.norm.lo); };  // == fl(u / max), ct_norm_constants
+    int lo = 0, hi = maxc + 1;  // first code with norm >= lower
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (norm(mid) >= a.lower) hi = mid; else lo = mid + 1; }
+    const int code_lo = lo;
+    lo = 0; hi = maxc + 1;      // first code with norm > upper
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (norm(mid) > a.upper) hi = mid; else lo = mid + 1; }
+    const int code_hi = lo - 1;
+    if (code_lo > code_hi) return;
+    const double kk = sqrt((double)weight_scale * 1.4426950408889634);
+    a.code_rcp = rcp;
+    a.code_step = step;
+    a.code_inv_step = (float)(1.0 / (double)step);
+    a.code_lo = (float)code_lo;
+    a.code_hi = (float)code_hi;
+    a.code_dk_mul = (float)(kk / (double)max_code);
+    a.code_dk_add = (float)(-0.5 * kk);
+    a.code_domain = 1;
+}
+}  // namespace ct
 
 extern "C" int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float max_code, int32_t n_images,
                                     const ct_geometry *geom, const float *std_dev, const ct_icrf *icrf,
@@ -1162,11 +1311,13 @@ extern "C" int ct_pair_residual_fwd(const void *stack_dev, int32_t dtype, float 
 #ifndef CT_PAIRS_MINIMAL
         case CT_DTYPE_U8:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            fill_code_domain(a, dtype, max_code, icrf->interp, params->std_mode, params->weight_scale);
             return fwd_dispatch<uint8_t>(a, icrf->interp, params->std_mode, level, s);
         case CT_DTYPE_F32: return fwd_dispatch<float>(a, icrf->interp, params->std_mode, level, s);
 #endif
         case CT_DTYPE_U16:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            fill_code_domain(a, dtype, max_code, icrf->interp, params->std_mode, params->weight_scale);
             return fwd_dispatch<uint16_t>(a, icrf->interp, params->std_mode, level, s);
     }
     return CT_ERR_UNSUPPORTED;
@@ -1208,11 +1359,13 @@ extern "C" int ct_pair_residual_bwd(const void *stack_dev, int32_t dtype, float 
 #ifndef CT_PAIRS_MINIMAL
         case CT_DTYPE_U8:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            fill_code_domain(a, dtype, max_code, icrf->interp, prm.std_mode, prm.weight_scale);
             return bwd_dispatch<uint8_t>(a, icrf->interp, prm.std_mode, workspace_dev, (size_t)workspace_bytes, s);
         case CT_DTYPE_F32: return bwd_dispatch<float>(a, icrf->interp, prm.std_mode, workspace_dev, (size_t)workspace_bytes, s);
 #endif
         case CT_DTYPE_U16:
             if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+            fill_code_domain(a, dtype, max_code, icrf->interp, prm.std_mode, prm.weight_scale);
             return bwd_dispatch<uint16_t>(a, icrf->interp, prm.std_mode, workspace_dev, (size_t)workspace_bytes, s);
     }
     return CT_ERR_UNSUPPORTED;
