@@ -43,7 +43,11 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
         raise ValueError("Batch size must be larger than 1.")
     dev = resolve_device(device)
     if optimizers is None:
-        optimizers = [torch.optim.Adam(icrf_model.channel_params(c), lr=1e-3, amsgrad=False) for c in range(channels)]
+        # the reference's defaults (icrf_training.py:64-66); on the GPU the fused implementation does each update in one
+        # kernel instead of seven (same update rule; 21 fewer launches per step with three channels)
+        fused = all(p.is_cuda for c in range(channels) for p in icrf_model.channel_params(c))
+        optimizers = [torch.optim.Adam(icrf_model.channel_params(c), lr=1e-3, amsgrad=False, **({"fused": True} if fused else {}))
+                      for c in range(channels)]
     for opt in optimizers:
         expect(opt, Optimizer, "optimizers[...]")
     previous_lrs = [pg["lr"] for opt in optimizers for pg in opt.param_groups]

@@ -25,6 +25,6 @@ for p in ("p1", "p2", "p3"):
             if key not in seen:
                 seen.add(key); cnt[k] += 1
         for k in agg:
-            if "merge_kernel" in k:
+            if "merge_" in k and "kernel" in k:
                 print(p, k[-40:], "dispatches", cnt[k], {c: "%.4g" % (v / cnt[k]) for c, v in agg[k].items()})
 PY
