@@ -153,10 +153,10 @@ extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp
     static std::mutex mu;
     static float cached_max = 0.0f, cached_rcp = 0.0f;
     static int cached_L = 0, cached_rc = CT_ERR_UNSUPPORTED;
-    uint32_t mul = 0;
-    float step = 0.0f;
-    const int rc0 = ct_pivot_index_constants(max_code, n_points, &mul, &step);  // step integral, integer form verified
-    if (rc0 != CT_OK) return rc0;
+    if (!(max_code >= 1.0f) || max_code > 65535.0f || floorf(max_code) != max_code || n_points < 2)
+        return CT_ERR_UNSUPPORTED;
+    if (n_points - 1 > (int)max_code || (int)max_code % (n_points - 1) != 0) return CT_ERR_UNSUPPORTED;  // whole steps only
+    const float step = (float)((int)max_code / (n_points - 1));
     std::lock_guard<std::mutex> lock(mu);
     if (cached_max != max_code || cached_L != n_points) {
         const int maxc = (int)max_code, top = n_points - 1;

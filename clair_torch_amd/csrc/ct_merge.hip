@@ -1112,10 +1112,14 @@ static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_poin
     px->index_mul = 0;
     px->index_rcp = 1.0f;
     if (interp == CT_INTERP_LINEAR) {
-        if (ct_pivot_index_constants(max_code, n_points, &px->index_mul, &px->step) != CT_OK) return false;
-        if (dtype == CT_DTYPE_U8 && px->step != 1.0f) return false;   // uint8 kernel: the code is the index
-        if (dtype == CT_DTYPE_U16 && px->index_mul == 0) return false;
-        if (CT_PIVOT_TYPED_LOAD && ct_pivot_floor_constants(max_code, n_points, &px->index_rcp) != CT_OK) return false;
+        if (CT_PIVOT_TYPED_LOAD) {  // any whole step: the interval comes from the round-down FMA on the float code
+            if (ct_pivot_floor_constants(max_code, n_points, &px->index_rcp) != CT_OK) return false;
+            px->step = (float)((int)max_code / (n_points - 1));
+        } else {
+            if (ct_pivot_index_constants(max_code, n_points, &px->index_mul, &px->step) != CT_OK) return false;
+            if (dtype == CT_DTYPE_U8 && px->step != 1.0f) return false;   // raw uint8 codes: the code is the index
+            if (dtype == CT_DTYPE_U16 && px->index_mul == 0) return false;
+        }
     }
     return true;
 }

@@ -1249,7 +1249,6 @@ static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, con
 }  // namespace ct
 
 extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
-extern "C" int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
 extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp_step);
 
 namespace ct {
@@ -1262,10 +1261,9 @@ static void fill_code_domain(PairArgs &a, int32_t dtype, float max_code, int int
     a.code_domain = 0;
     if (interp != CT_INTERP_LINEAR || std_mode != CT_STD_NONE) return;
     if (max_code != (dtype == CT_DTYPE_U8 ? 255.0f : 65535.0f)) return;
-    uint32_t mul = 0;
-    float step = 0.0f, rcp = 0.0f;
-    if (ct_pivot_index_constants(max_code, a.n_points, &mul, &step) != CT_OK) return;
-    if (ct_pivot_floor_constants(max_code, a.n_points, &rcp) != CT_OK) return;
+    float rcp = 0.0f;
+    if (ct_pivot_floor_constants(max_code, a.n_points, &rcp) != CT_OK) return;  // whole steps, verified for every code
+    const float step = (float)((int)max_code / (a.n_points - 1));
     const int maxc = (int)max_code;
     auto norm = [&](int u) { const float uf = (float)u; return fmaf(uf, a.norm.hi, uf * a.norm.lo); };  // == fl(u / max), ct_norm_constants
     int lo = 0, hi = maxc + 1;  // first code with norm >= lower

@@ -75,6 +75,32 @@ def test_code_normalisation_constants_are_exact(lib, max_code):
     assert lib.ct_norm_constants(0.5, ctypes.byref(hi), ctypes.byref(lo)) != 0
 
 
+@pytest.mark.parametrize("max_code,n_points,ok", [(65535, 256, True), (65535, 2, True), (65535, 4, True), (65535, 16, True),
+                                                 (65535, 52, True), (65535, 258, True), (65535, 772, False), (65535, 65536, True),
+                                                 (255, 256, True), (255, 2, True), (255, 16, True), (255, 52, True), (255, 86, True),
+                                                 (65535, 100, False), (65535, 1000, False), (255, 100, False), (4095, 256, False)])
+def test_round_down_fma_interval_constants(lib, max_code, n_points, ok):
+    """ct_pivot_floor_constants: the LUT interval the typed-load kernels form from the code held as a float --
+    floor(code * r) with r = 1 / step rounded UP (what one FMA under round-toward-minus-infinity against 1.5 * 2^23 leaves
+    in the mantissa) -- equals the reference's float32 interval floor(fl(fl(u / max) * (L - 1))) (base.py:166-168) for
+    every code; refused when the step is not a whole number of codes, and for L = 772 (step 85), where the reference's own
+    two roundings put exact multiples of the step one interval low."""
+    r = ctypes.c_float()
+    lib.ct_pivot_floor_constants.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    rc = lib.ct_pivot_floor_constants(float(max_code), n_points, ctypes.byref(r))
+    assert (rc == 0) == ok
+    u = np.arange(max_code + 1)
+    ref = np.floor((u.astype(np.float32) / np.float32(max_code)) * np.float32(n_points - 1))
+    if not ok:
+        if max_code % (n_points - 1) == 0:  # a whole step, refused because the reference's index is not u // step
+            assert not np.array_equal(ref, u // (max_code // (n_points - 1)))
+        return
+    step = max_code // (n_points - 1)
+    assert step * (n_points - 1) == max_code and np.float64(r.value) >= 1.0 / step
+    got = np.floor(u.astype(np.float64) * np.float64(r.value))  # exact: 16-bit code times a 24-bit significand
+    assert np.array_equal(got, ref) and np.array_equal(got, u // step) and got.max() == n_points - 1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from clair_torch_amd import _native
     monkeypatch.setattr(_native, "_lib", None)

@@ -291,6 +291,46 @@ def test_merge_unusual_lut_sizes(dev, n_points, dtype):
         assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"L={n_points} {mode} std")
 
 
+@pytest.mark.parametrize("dtype,n_points", [("u16", 2), ("u16", 4), ("u16", 16), ("u16", 52), ("u16", 258), ("u16", 772),
+                                            ("u8", 2), ("u8", 16), ("u8", 52), ("u8", 86), ("u8", 256)])
+@pytest.mark.parametrize("shape", [(3, 16, 24), (3, 7, 9)])
+def test_merge_whole_step_lut_sizes_on_the_typed_load_kernel(dev, dtype, n_points, shape):
+    """LUT lengths whose step max_code / (L-1) is a whole number of codes go through ct::merge_pivot_kernel: the codes
+    arrive as floats from typed buffer loads and the interval is one round-down FMA (ct_pivot_floor_constants).  Packets of
+    four and the ragged one-element path (7 x 9 planes), knots, their neighbours and both ends included, first batch and
+    streamed state, against the float64 oracle."""
+    from clair_torch_amd import _native as nv
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    maxc = 255 if dtype == "u8" else 65535
+    step = maxc // (n_points - 1)
+    name = nv.load().ct_hdr_merge_kernel_name(nv.DTYPE_U8 if dtype == "u8" else nv.DTYPE_U16, float(maxc), nv.INTERP_LINEAR,
+                                              n_points, nv.MERGE_FIRST_BATCH | nv.MERGE_FINALIZE).decode()
+    # ... unless the reference's own float32 index is not code // step (L = 772: the proof refuses, the generic kernel runs)
+    import ctypes
+    rcp = ctypes.c_float()
+    nv.load().ct_pivot_floor_constants.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    proven = nv.load().ct_pivot_floor_constants(float(maxc), n_points, ctypes.byref(rcp)) == 0
+    assert proven == (n_points != 772)
+    assert ("merge_pivot_kernel" in name and "typed buffer loads" in name) == proven
+    rng = np.random.default_rng(1000 * n_points + shape[1])
+    n = 6
+    codes = rng.integers(0, maxc + 1, size=(n,) + shape).astype(np.uint8 if dtype == "u8" else np.uint16)
+    flat = codes.reshape(-1)
+    knots = np.array([0, maxc, step, step - 1 if step > 1 else 0, min(maxc, step + 1), maxc - step, maxc - 1,
+                      (n_points - 2) * step, (n_points // 2) * step, max(0, (n_points // 2) * step - 1)])
+    flat[:knots.size] = knots.astype(flat.dtype)
+    x = oc.normalize_codes(codes)
+    t = 0.001 * 2.0 ** np.arange(n)
+    lut = np.stack([np.linspace(0, 1, n_points, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
+    for part in ([n], [2, 4]):
+        mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, "linear", True, part)
+        mean, std = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, lut=torch.from_numpy(lut).to(dev),
+                                   interp="linear", std_mode="multiplier", std_value=0.05)
+        assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"{dtype} L={n_points} typed mean")
+        assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"{dtype} L={n_points} typed std")
+
+
 @pytest.mark.parametrize("mode", ["linear", "lookup", "catmull"])
 def test_codes_above_max_code_are_clamped_like_the_reference(dev, mode):
     """12-bit data in a uint16 container, Normalize(4095): codes above max_code give x > 1, which the reference's model
