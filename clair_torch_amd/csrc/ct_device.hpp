@@ -151,6 +151,45 @@ __device__ __forceinline__ int lut_row(uint32_t q_global, int channel, int C)
         return (int)(q_global % (uint32_t)C);
 }
 
+// Typed buffer loads: with DATA_FORMAT 16_16_16_16 / 8_8_8_8 (16 / 8 for single codes) and NUM_FORMAT USCALED in the
+// descriptor, buffer_load_format_xyzw delivers (float)code for four packed integer codes -- the conversion happens in the
+// texture-data path between L1 and the registers, which is idle in these kernels, instead of one half-rate v_cvt per
+// sample on the VALU.  Exact for every code and at the streaming rate of a plain load (tools/typed_load_probe.hip checks
+// all 65 536 codes in every component on the device; profiles/r02_typed_load_probe.log).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ f32x4_t raw_buffer_load_format_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
+__device__ float raw_buffer_load_format_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.f32");
+// word 3 of the gfx9 buffer descriptor: DST_SEL_{X,Y,Z,W} = R,G,B,A (4,5,6,7) | NUM_FORMAT << 12 (2 = USCALED) |
+// DATA_FORMAT << 15 (1 = 8, 2 = 16, 10 = 8_8_8_8, 12 = 16_16_16_16)
+template <typename T, int V>
+constexpr uint32_t uscaled_format_word()
+{
+    static_assert((V == 1 || V == 4) && (sizeof(T) == 1 || sizeof(T) == 2), "typed loads: 1 or 4 codes of 8 or 16 bits");
+    constexpr uint32_t sel = V == 4 ? (4u | (5u << 3) | (6u << 6) | (7u << 9)) : 4u;
+    constexpr uint32_t dfmt = V == 4 ? (sizeof(T) == 2 ? 12u : 10u) : (sizeof(T) == 2 ? 2u : 1u);
+    return sel | (2u << 12) | (dfmt << 15);
+}
+// V = 1 or 4 codes at `base` (wave-uniform) + `offset` bytes (per thread, 32 bits: the descriptor spans 4 GiB from the base)
+template <typename T, int V, int AUX = 0>
+__device__ __forceinline__ void load_codes_as_float(uint64_t base, uint32_t offset, float (&out)[V])
+{
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, 0xffffffff, (int)uscaled_format_word<T, V>());
+    if constexpr (V == 4) {
+        const f32x4_t v = raw_buffer_load_format_v4f32(rsrc, (int)offset, 0, AUX);
+        out[0] = v.x;
+        out[1] = v.y;
+        out[2] = v.z;
+        out[3] = v.w;
+    } else {
+        out[0] = raw_buffer_load_format_f32(rsrc, (int)offset, 0, AUX);
+    }
+}
+// the reference's CastTo(float32) + Normalize(0, max) on a code that is already a float
+__device__ __forceinline__ float code_to_pixel(float u, NormConst nc) { return __builtin_fmaf(u, nc.hi, u * nc.lo); }
+
 // LUT interval of V codes held as floats: floor(px / step) = mantissa of fma(px, r, 1.5 * 2^23) when that one FMA rounds
 // toward minus infinity (r = 1 / step rounded up, so exact multiples of the step do not fall below their interval; the
 // error of px * r stays below 1.6e-5 < 1 / step).  FP_ROUND of the MODE register is switched for exactly these V

@@ -62,13 +62,35 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
     }
     for (uint32_t f = blockIdx.y; f < a.n_frames; f += gridDim.y) {
         const int64_t off = (int64_t)f * a.image_stride + q0;
-        const LPacket<T, V> pk = *reinterpret_cast<const LPacket<T, V> *>(static_cast<const T *>(a.frames) + off);
+        // integer frames: typed buffer loads deliver the codes as floats (ct_device.hpp) -- frame base in SGPRs, 32-bit
+        // per-thread byte offset, no v_cvt; float frames: plain 16-byte loads
+        float xin[V];
+        if constexpr (sizeof(T) != 4) {
+            static_assert(V == 1 || V % 4 == 0, "packets of 1, 4 or 8 codes");
+            const uint64_t base = reinterpret_cast<uint64_t>(a.frames) + (uint64_t)((int64_t)f * a.image_stride * (int64_t)sizeof(T));
+            if constexpr (V == 1) {
+                load_codes_as_float<T, 1>(base, q0 * (uint32_t)sizeof(T), xin);
+            } else {
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) {
+                    float part[4];
+                    load_codes_as_float<T, 4>(base, (q0 + 4u * h) * (uint32_t)sizeof(T), part);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xin[4 * h + k] = part[k];
+                }
+            }
+        } else {
+            const LPacket<T, V> pk = *reinterpret_cast<const LPacket<T, V> *>(static_cast<const T *>(a.frames) + off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) xin[e] = pk.v[e];
+        }
         LPacket<float, V> sp;
         if constexpr (STD == CT_STD_EXPLICIT) sp = *reinterpret_cast<const LPacket<float, V> *>(a.std_stack + off);
         LPacket<float, V> lo, so;
+        [[maybe_unused]] bool tiny = false;  // some 0 < |grad * std| < 1e-18 in this packet
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float x = to_pixel<T>(pk.v[e], a.norm);
+            const float x = sizeof(T) != 4 ? code_to_pixel(xin[e], a.norm) : xin[e];
             float dfdx;
             lo.v[e] = icrf_sample<INTERP, true, kRanged>(x, lds + row_off[e], top, dfdx);
             if constexpr (WRITE_STD) {
@@ -77,12 +99,22 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
                 if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;  // datasets/base.py:133
                 if constexpr (STD == CT_STD_CONSTANT) sigma = a.std_value;
                 // linearization.py:106,132: sqrt((grad * std) ** 2).  In binary floating point the correctly rounded
-                // square root of a correctly rounded square is |.| exactly unless the square underflows, so the
-                // ~12-instruction sqrtf expansion only runs for 0 < |gs| < 1e-18 (practically never; wave-uniform skip)
-                const float gs = dfdx * sigma, ags = fabsf(gs);
-                float sd = ags;
-                if (ags < 1e-18f && ags != 0.0f) sd = sqrtf(gs * gs);
-                so.v[e] = STD == CT_STD_NONE ? 0.0f : sd;
+                // square root of a correctly rounded square is |.| exactly unless the square underflows, so the sqrtf
+                // expansion (~18 instructions) is only needed for 0 < |gs| < 1e-18
+                const float ags = fabsf(dfdx * sigma);
+                so.v[e] = STD == CT_STD_NONE ? 0.0f : ags;
+                if constexpr (STD != CT_STD_NONE) tiny |= ags < 1e-18f && ags != 0.0f;
+            }
+        }
+        if constexpr (WRITE_STD && STD != CT_STD_NONE) {
+            // ... and runs behind a wave-uniform branch (practically never taken).  Written as a per-element `if` the
+            // compiler if-converts it and every sample pays for the expansion: a third of this kernel's VALU work.
+            if (__builtin_expect(__any(tiny), 0)) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float g = so.v[e];  // |gs|; the square does not see the sign
+                    if (g < 1e-18f && g != 0.0f) so.v[e] = sqrtf(g * g);
+                }
             }
         }
         if (a.tile.layout != CT_LAYOUT_NCHW) {  // interleaved input -> planar outputs, element-wise stores

@@ -455,41 +455,16 @@ __device__ __forceinline__ P load_buffer(uint64_t base, uint32_t offset)
     return out;
 }
 
-// Typed buffer loads (round 2): with DATA_FORMAT 16_16_16_16 / 8_8_8_8 (16 / 8 for single codes) and NUM_FORMAT USCALED
-// in the descriptor, buffer_load_format_xyzw delivers (float)code for the four packed codes -- the conversion happens
-// in the texture-data path on the way to the registers, which is idle here, instead of one half-rate
-// v_cvt_f32_u32_sdwa per sample on the VALU, which is the unit this kernel is bound by.  Exact for every code
-// (tools/typed_load_probe.hip checks all 65 536 in every component on the device).
+// Typed buffer loads (load_codes_as_float, ct_device.hpp): the codes reach the registers as floats, converted in the
+// texture-data path instead of by one half-rate v_cvt_f32_u32_sdwa per sample on the VALU this kernel is bound by.
 #ifndef CT_PIVOT_TYPED_LOAD
 #define CT_PIVOT_TYPED_LOAD 1
 #endif
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ f32x4_t raw_buffer_load_format_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
-__device__ float raw_buffer_load_format_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
-    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.f32");
-// word 3 of the gfx9 buffer descriptor: DST_SEL_{X,Y,Z,W} = R,G,B,A (4,5,6,7) | NUM_FORMAT << 12 (2 = USCALED) |
-// DATA_FORMAT << 15 (1 = 8, 2 = 16, 10 = 8_8_8_8, 12 = 16_16_16_16)
-template <typename T, int V>
-constexpr uint32_t uscaled_format_word()
-{
-    static_assert((V == 1 || V == 4) && (sizeof(T) == 1 || sizeof(T) == 2), "typed loads: 1 or 4 codes of 8 or 16 bits");
-    constexpr uint32_t sel = V == 4 ? (4u | (5u << 3) | (6u << 6) | (7u << 9)) : 4u;
-    constexpr uint32_t dfmt = V == 4 ? (sizeof(T) == 2 ? 12u : 10u) : (sizeof(T) == 2 ? 2u : 1u);
-    return sel | (2u << 12) | (dfmt << 15);
-}
 template <typename T, int V>
 __device__ __forceinline__ Packet<float, V> load_codes_as_float(uint64_t base, uint32_t offset)
 {
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, 0xffffffff, (int)uscaled_format_word<T, V>());
     Packet<float, V> out;
-    if constexpr (V == 4) {
-        const f32x4_t v = raw_buffer_load_format_v4f32(rsrc, (int)offset, 0, CT_STACK_LOAD_AUX);
-        __builtin_memcpy(&out, &v, sizeof(out));
-    } else {
-        out.v[0] = raw_buffer_load_format_f32(rsrc, (int)offset, 0, CT_STACK_LOAD_AUX);
-    }
+    load_codes_as_float<T, V, CT_STACK_LOAD_AUX>(base, offset, out.v);
     return out;
 }
 
