@@ -143,6 +143,35 @@ def test_linearize_streamed_frames_vs_oracle(dev):
         assert np.array_equal(lin.cpu().numpy(), lin_o) and np.array_equal(sd.cpu().numpy(), sd_o)
 
 
+def test_linearize_std_whose_square_underflows(dev):
+    """linearization.py:106,132 forms sqrt((grad * std) ** 2) in float32: for 0 < |grad * std| < ~1e-19 the square is
+    denormal or zero and the result is NOT |grad * std|.  The kernel takes |.| on the fast path and the correctly rounded
+    sqrtf of the rounded square behind a wave-uniform branch; wavefronts that mix ordinary and underflowing samples, a
+    constant sigma below the threshold and one far below it (square flushes to zero), bit for bit against the oracle."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(18)
+    lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(p) for p in (2.2, 2.4, 2.6)])
+    codes = rng.integers(0, 65536, size=(2, 3, 33, 64)).astype(np.uint16)
+    x = oc.normalize_codes(codes)
+    sigma = np.full(codes.shape, 0.01, dtype=np.float32)
+    pick = rng.random(codes.shape)
+    sigma[pick < 0.02] = np.float32(3e-20)   # square is a float32 denormal: precision lost, sqrt != |.|
+    sigma[pick < 0.01] = np.float32(1e-30)   # square flushes to zero
+    sigma[0, 0, :2] = np.float32(2e-19)      # whole rows (whole wavefronts) in the slow branch
+    lin_o, sd_o = oc.linearize_std(x, sigma, lut, "linear")
+    assert (sd_o != np.abs(sd_o)).sum() == 0 and ((sd_o == 0) & (sigma > 0) & (x > 0) & (x < 1)).any()
+    lin, sd = ops.linearize_frames(torch.from_numpy(codes).to(dev), torch.from_numpy(lut).to(dev), "linear",
+                                   std=torch.from_numpy(sigma).to(dev))
+    assert np.array_equal(lin.cpu().numpy(), lin_o) and np.array_equal(sd.cpu().numpy(), sd_o)
+    for value in (4e-20, 1e-30):
+        const = np.full(codes.shape, value, dtype=np.float32)
+        _, sd_o = oc.linearize_std(x, const, lut, "linear")
+        _, sd = ops.linearize_frames(torch.from_numpy(codes).to(dev), torch.from_numpy(lut).to(dev), "linear",
+                                     std_mode="constant", std_value=value)
+        assert np.array_equal(sd.cpu().numpy(), sd_o)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_linearize_codes_above_max_code(dev, mode):
     """uint16 codes above max_code = 4095 (x > 1): value clamps to the top of the LUT, the derivative (and with it the
