@@ -5,7 +5,7 @@ import pytest
 import torch
 from torch.utils.data import DataLoader
 
-from _util import assert_parity, golden
+from _util import assert_parity, golden, rel_norm
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,54 @@ def test_pair_sums_vs_golden(dev, as_codes, sname, mode):
             assert_parity(sd.cpu().numpy(), g[key + "_spatial_std"], rtol=1e-5, norm_tol=2e-6, what=key + " std")
             if sname != "none":
                 assert_parity(err.cpu().numpy(), g[key + "_spatial_err"], rtol=1e-5, norm_tol=2e-6, what=key + " err")
+
+
+@pytest.mark.parametrize("n_points", [256, 16, 52])
+@pytest.mark.parametrize("shape", [(3, 24, 64), (3, 7, 9)])
+def test_code_domain_staging_equals_generic_staging(dev, n_points, shape):
+    """uint16 stacks at full range with a whole-step LINEAR curve are staged in the code domain (interval by the round-down
+    FMA, f = g[i] + slope (code - i step), mask as a code interval); the same data as normalised float32 goes through the
+    generic staging (the reference's float32 order).  Forward sums, mask popcounts (exactly) and the LUT gradient must
+    agree, codes ON the validity thresholds, one below / above them and on LUT knots included; vectorised and ragged tiles."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(n_points * 100 + shape[1])
+    n = 9
+    # random codes: residuals of order one.  (On a synthetic, perfectly consistent stack the residuals sit at the uint16
+    # quantisation level and sign(residual) -- hence the gradient -- flips with ANY 1e-7 change of the linearized values,
+    # in the reference's own float32 arithmetic as much as here.)
+    codes = rng.integers(0, 65536, size=(n,) + shape).astype(np.uint16)
+    exposures = 0.002 * 1.3 ** np.arange(n)
+    step = 65535 // (n_points - 1)
+    lo, hi = 1 / 255, 254 / 255
+    u = np.arange(65536, dtype=np.float32) / np.float32(65535.0)
+    c_lo, c_hi = int(np.argmax(u >= np.float32(lo))), int(65535 - np.argmax(u[::-1] <= np.float32(hi)))
+    special = np.array([c_lo - 1, c_lo, c_lo + 1, c_hi - 1, c_hi, c_hi + 1, 0, 65535, step, step - 1, step + 1, 65535 - step,
+                        (n_points // 2) * step, (n_points // 2) * step - 1], dtype=np.uint16)
+    codes.reshape(-1)[:special.size] = special
+    codes[3].reshape(-1)[:special.size] = special[::-1]
+    x = oc.normalize_codes(codes)
+    t = torch.tensor(exposures, dtype=torch.float64)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n, dev)
+    lut = torch.stack([torch.linspace(0, 1, n_points) ** p for p in (1.8, 2.2, 2.6)]).to(dev)
+    for rel in (True, False):
+        kw = dict(lut=lut, interp="linear", lower=lo, upper=hi, use_relative=rel, use_unc_weight=False)
+        s_code = ops.pair_residual_sums(torch.from_numpy(codes).to(dev), pairs, level=1, **kw)
+        s_float = ops.pair_residual_sums(torch.from_numpy(x).to(dev), pairs, level=1, **kw)
+        assert torch.equal(s_code[..., 4], s_float[..., 4]), "mask popcounts differ"
+        assert_parity(s_code[..., :3].cpu().numpy(), s_float[..., :3].cpu().numpy(), rtol=1e-5, norm_tol=2e-6,
+                      what=f"code-domain vs generic sums L={n_points} {'rel' if rel else 'abs'}")
+        coef = torch.from_numpy(rng.uniform(0.5, 1.5, size=(pairs.n_pairs, 3))).to(dev)  # one sign: LUT bins do not cancel
+        g_code = ops.pair_residual_lut_grad(torch.from_numpy(codes).to(dev), pairs, coef, **kw)
+        g_float = ops.pair_residual_lut_grad(torch.from_numpy(x).to(dev), pairs, coef, **kw)
+        # most LUT bins of so small an image are empty or hold a handful of +- terms: norm-wise, and element-wise
+        # against the largest entry (the median the usual criterion scales by is ~0 here)
+        gc, gf = g_code.cpu().numpy(), g_float.cpu().numpy()
+        # (a residual within 1e-7 of zero changes sign between the two stagings and moves its +-weight: a few in 1e5 samples)
+        assert rel_norm(gc, gf) <= 2e-5, (n_points, rel, rel_norm(gc, gf))
+        assert np.abs(gc - gf).max() <= 1e-4 * np.abs(gf).max(), (n_points, rel, np.abs(gc - gf).max() / np.abs(gf).max())
 
 
 @pytest.mark.parametrize("mode", ["linear", "catmull"])
