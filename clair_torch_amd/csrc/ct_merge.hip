@@ -369,16 +369,18 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
 //       checks its own conditioning (sum of |terms| against the result); a wavefront with an ill-conditioned element
 //       runs the batch a second time about the now known mean (explicit fallback, exact to float32 rounding).
 //   * the batch mean is accumulated about the same pivot: sum w (y - p), mean = p + ..., in float64 only at the end;
-//   * LUT entry {g[i], (g[i+1]-g[i]) / step, i * step, (g[i+1]-g[i]) * (L-1) * kk / K} indexed by floor(code / step)
-//     = mul_hi_u24(code, M) (one SDWA instruction on the packed codes, host-verified for every code against the
-//     reference's float32 index); f = g + slope * (code - i * step): no float coordinate, no fract, no float -> int;
+//   * the codes reach the registers as floats through typed buffer loads (conversion in the texture-data path, not on
+//     the VALU; ct_device.hpp), the LUT interval floor(code / step) is the mantissa of ONE FMA that rounds toward minus
+//     infinity (host-verified for every code against the reference's float32 index), and the 8-byte LUT entry {A, S}
+//     gives f = A + S * code in one more FMA: no float coordinate, no fract, no float -> int, no integer -> float;
 //   * persistent workgroups: the table and 1/t are staged once per workgroup, not once per 1024 elements;
 //   * the epilogue has no float64 division (one v_rcp_f32 + Newton step, shared by the mean and the variance).
 // LOOKUP (b = a y exactly: the whole variance is the cancelling part) and CATMULL stay on the float64 kernel above.
-// Element e of a packet of raw codes as float, and its LUT interval, straight from the packed dwords: on uint16 both
-// are one SDWA instruction (v_cvt_f32_u32 / v_mul_hi_u32_u24 with a word select), so the codes are never unpacked.
-// (Left to itself LLVM unpacks with v_and / v_lshrrev first because the code has two users, and turns
-// ((code * M) >> 32) << 4 into a 64-bit alignbit + and + add.)
+// Raw-code build (CT_PIVOT_TYPED_LOAD=0, kept for A/B: profiles/r02_typed_load_ab.log): element e of a packet of raw
+// codes as float, and its LUT interval, straight from the packed dwords -- on uint16 both are one SDWA instruction
+// (v_cvt_f32_u32 / v_mul_hi_u32_u24 with a word select), so the codes are never unpacked.  (Left to itself LLVM unpacks
+// with v_and / v_lshrrev first because the code has two users, and turns ((code * M) >> 32) << 4 into a 64-bit alignbit
+// + and + add.)
 template <int WORD>
 __device__ __forceinline__ float word_to_float(uint32_t dw)
 {

@@ -9,7 +9,10 @@
 //
 // Structure (all kernels): a workgroup walks tiles of TP pixels of ONE channel plane.  Phase 1 linearizes all N
 // samples of the tile once and parks (f(x), Gaussian weight -- -inf when the sample is outside [lo, hi] --[, LUT
-// coordinate, linearized std]) in LDS; phase 2 evaluates the pairs out of LDS.
+// coordinate, linearized std]) in LDS; phase 2 evaluates the pairs out of LDS.  Integer stacks at full range with a
+// whole-step LINEAR curve and no uncertainties are staged in the CODE DOMAIN (code_domain_sample: interval by one
+// round-down FMA on the float code, f = g[i] + slope (code - i step), mask as a code interval: ~12 instead of ~33
+// instructions per staged sample); everything else keeps the reference's float32 operation order.
 //   forward       : thread <-> pair(s); each thread walks the tile's columns and keeps its pairs' sums in registers
 //                   (float32 inside a tile, float64 across tiles), one float64 atomic per sum per workgroup at the end.
 //   backward      : wavefront <-> sample i, lane <-> column; each pair is evaluated once from its first sample, the
