@@ -452,7 +452,10 @@ def test_lane_backward_kernel(dev, interp, relative, n, stops, h, w, kind):
                              use_unc_weight=False, max_code=max_code)
     grad = torch.autograd.grad(lin.sum(), lut)[0]
     assert_parity(sp.cpu().numpy(), sp_o.detach().numpy(), rtol=1e-5, norm_tol=2e-6, what="lane: spatial means")
-    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=2e-6, elem_tol=2e-5, what="lane: LUT gradient vs oracle")
+    # norm 5e-6: the comparand is the eager float32 autograd, whose index_put accumulation order -- and with it the
+    # gradient -- depends on the CPU thread count: 2.6e-6 norm-wise between 8 and 3 threads on the (57, u8, catmull,
+    # absolute) case, measured; the kernel (float64 accumulators, deterministic) observed 1.6e-6 .. 2.2e-6 against it
+    assert_parity(grad.cpu().numpy(), grad_o.numpy(), norm_tol=5e-6, elem_tol=2e-5, what="lane: LUT gradient vs oracle")
 
 
 def test_lane_backward_broken_promise_falls_back(dev):
