@@ -23,7 +23,7 @@ EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linear
            "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_pair_residual_bwd_workspace", "ct_flatfield_sums",
            "ct_flatfield_apply", "ct_video_stats_batch", "ct_dark_field_blur", "ct_hdr_merge_kernel_name",
            "ct_merge_set_retry_counter", "ct_norm_constants", "ct_index_constants", "ct_pivot_index_constants",
-           "ct_pivot_floor_constants")
+           "ct_pivot_floor_constants", "ct_band_stats", "ct_band_stats_workspace")
 
 
 class Geometry(ctypes.Structure):
@@ -94,6 +94,10 @@ def load():
     lib.ct_flatfield_apply.argtypes = [vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i64, vp]
     lib.ct_dark_field_blur.restype = i32
     lib.ct_dark_field_blur.argtypes = [vp, i32, f32, i32, gp, vp, vp, i32, f32, vp, vp, i32, f32, f32, vp, vp, vp]
+    lib.ct_band_stats_workspace.restype = i64
+    lib.ct_band_stats_workspace.argtypes = [i32]
+    lib.ct_band_stats.restype = i32
+    lib.ct_band_stats.argtypes = [vp, vp, i32, i64, vp, i64, vp, vp]
     lib.ct_video_stats_batch.restype = i32
     lib.ct_video_stats_batch.argtypes = [vp, i32, f32, i32, gp, ip, f32, vp, vp, vp]
     if lib.ct_abi_version() != ABI_VERSION:

@@ -84,6 +84,42 @@ __device__ __forceinline__ float load_pixel(const void *base, int64_t idx, NormC
     return to_pixel<T>(static_cast<const T *>(base)[idx], nc);
 }
 
+// element e of a packed raw vector as a float: one conversion straight from the packed dword (no unpacking)
+__device__ __forceinline__ float raw_code_as_float(uint32_t v, int e) { return (float)((v >> (8 * e)) & 0xffu); }  // v_cvt_f32_ubyteN
+__device__ __forceinline__ float raw_code_as_float(uint2 v, int e)
+{
+    const uint32_t dw = e < 2 ? v.x : v.y;
+    float r;
+    if (e & 1)
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(dw));
+    else
+        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(dw));
+    return r;
+}
+__device__ __forceinline__ float raw_code_as_float(float4, int) { return 0.0f; }  // never used: float stacks are not code-domain
+
+// One sample of the code-domain staging: t = 1.5 * 2^23 + interval (floor_index_bits), px = the code as a float.
+//   f = g[i] + slope * (px - i * step)   offset exact, ONE rounding in the FMA: closer to the exact interpolant than the
+//                                        reference's own float32 order g0 * (1 - w) + g1 * w (three roundings), and equal
+//                                        to it bit for bit when step == 1
+//   gauss = exp2(-(px * mul + add)^2), -inf outside [code_lo, code_hi] (the reference's mask on the normalised value,
+//           translated to codes on the host with the reference's own float32 division)
+//   coordinate (backward) = i + (px - i * step) / step
+template <bool WANT_COORD>
+__device__ __forceinline__ float2 code_domain_sample(const PairArgs &a, const char *lut_lds, uint32_t row_constant, float t,
+                                                     float magic, float px, float &coord)
+{
+    const float2 g = *reinterpret_cast<const float2 *>(lut_lds + lds_entry_address(t, row_constant));
+    const float i0f = t - magic;                                // exact
+    const float off = __builtin_fmaf(i0f, -a.code_step, px);    // exact: an integer below step
+    const float lin = __builtin_fmaf(g.y, off, g.x);
+    const float dk = __builtin_fmaf(px, a.code_dk_mul, a.code_dk_add);
+    const float gw = __builtin_amdgcn_exp2f(-dk * dk);
+    const bool valid = __builtin_amdgcn_fmed3f(px, a.code_lo, a.code_hi) == px;
+    if constexpr (WANT_COORD) coord = __builtin_fmaf(off, a.code_inv_step, i0f);
+    return make_float2(lin, valid ? gw : -INFINITY);
+}
+
 // Phase 1 shared by both kernels: linearize every sample of the tile into LDS.
 //   val[n*pitch + px] = (f(x), gauss(x))   gauss = -inf when x is outside [lo, hi]: the pair weight g_i + g_j is then
 //                                          -inf as well and max(., 0) applies the pair mask in one instruction
@@ -197,42 +233,6 @@ template <> struct RawVec<float> { using type = float4; };
 __device__ __forceinline__ uint8_t raw_elem(uint32_t v, int e) { return (uint8_t)(v >> (8 * e)); }
 __device__ __forceinline__ uint16_t raw_elem(uint2 v, int e) { return (uint16_t)((e < 2 ? v.x : v.y) >> (16 * (e & 1))); }
 __device__ __forceinline__ float raw_elem(float4 v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
-
-// element e of a packed raw vector as a float: one conversion straight from the packed dword (no unpacking)
-__device__ __forceinline__ float raw_code_as_float(uint32_t v, int e) { return (float)((v >> (8 * e)) & 0xffu); }  // v_cvt_f32_ubyteN
-__device__ __forceinline__ float raw_code_as_float(uint2 v, int e)
-{
-    const uint32_t dw = e < 2 ? v.x : v.y;
-    float r;
-    if (e & 1)
-        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(dw));
-    else
-        asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(dw));
-    return r;
-}
-__device__ __forceinline__ float raw_code_as_float(float4, int) { return 0.0f; }  // never used: float stacks are not code-domain
-
-// One sample of the code-domain staging: t = 1.5 * 2^23 + interval (floor_index_bits), px = the code as a float.
-//   f = g[i] + slope * (px - i * step)   offset exact, ONE rounding in the FMA: closer to the exact interpolant than the
-//                                        reference's own float32 order g0 * (1 - w) + g1 * w (three roundings), and equal
-//                                        to it bit for bit when step == 1
-//   gauss = exp2(-(px * mul + add)^2), -inf outside [code_lo, code_hi] (the reference's mask on the normalised value,
-//           translated to codes on the host with the reference's own float32 division)
-//   coordinate (backward) = i + (px - i * step) / step
-template <bool WANT_COORD>
-__device__ __forceinline__ float2 code_domain_sample(const PairArgs &a, const char *lut_lds, uint32_t row_constant, float t,
-                                                     float magic, float px, float &coord)
-{
-    const float2 g = *reinterpret_cast<const float2 *>(lut_lds + lds_entry_address(t, row_constant));
-    const float i0f = t - magic;                                // exact
-    const float off = __builtin_fmaf(i0f, -a.code_step, px);    // exact: an integer below step
-    const float lin = __builtin_fmaf(g.y, off, g.x);
-    const float dk = __builtin_fmaf(px, a.code_dk_mul, a.code_dk_add);
-    const float gw = __builtin_amdgcn_exp2f(-dk * dk);
-    const bool valid = __builtin_amdgcn_fmed3f(px, a.code_lo, a.code_hi) == px;
-    if constexpr (WANT_COORD) coord = __builtin_fmaf(off, a.code_inv_step, i0f);
-    return make_float2(lin, valid ? gw : -INFINITY);
-}
 
 __device__ __forceinline__ int pixel_of_column(const PairArgs &a, int col)
 {

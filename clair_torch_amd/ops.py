@@ -380,6 +380,31 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
     return grad
 
 
+# ---- per-band statistics (BASELINE configuration C5) -------------------------------------------------------------
+def band_stats(mean: torch.Tensor, std: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ct_band_stats: (6, C) float64 = [min mean, max mean, sum mean, min std, max std, sum std] per channel of a merged
+    (C, H_band, W) band in ONE pass (``std`` None: the std rows are zero).  min / max / sum combine over row bands."""
+    _require_device(mean, "mean")
+    if mean.dtype != torch.float64 or mean.dim() != 3:
+        raise ValueError("mean must be a (C, H, W) float64 device tensor")
+    mean = mean.contiguous()
+    c = mean.shape[0]
+    plane = mean.shape[1] * mean.shape[2]
+    if std is not None:
+        _require_device(std, "std")
+        if std.dtype != torch.float32 or std.shape != mean.shape:
+            raise ValueError("std must be float32 with the mean's shape")
+        std = std.contiguous()
+    lib = nv.load()
+    ws_bytes = int(lib.ct_band_stats_workspace(c))
+    ws = torch.empty((ws_bytes // 8,), dtype=torch.float64, device=mean.device)
+    out = torch.empty((6, c), dtype=torch.float64, device=mean.device)
+    with torch.cuda.device(mean.device):
+        rc = lib.ct_band_stats(_ptr(mean), _ptr(std), c, plane, _ptr(ws), ws_bytes, _ptr(out), _stream(mean.device))
+    nv.check(rc, "ct_band_stats")
+    return out
+
+
 # ---- flat-field correction epilogues ----------------------------------------------------------------------------
 def flatfield_correct(value: torch.Tensor, var_or_std: Optional[torch.Tensor], flat: torch.Tensor,
                       flat_std: Optional[torch.Tensor], *, input_is_variance: bool, through_mean: bool,

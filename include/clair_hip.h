@@ -243,6 +243,18 @@ int ct_flatfield_apply(void *value_dev, int32_t value_is_f64, int64_t n_frames, 
                        void *stream);
 
 /*
+ * ct_band_stats -- per-channel statistics of one merged row band, the quantity BASELINE configuration C5 gathers over
+ * RCCL ("tile-sharded ... merge + uncertainty, RCCL gather of per-tile stats"; the reference has no such function: its
+ * script saves the merged image, scripts/run_hdr_merging.py:60-86).  One pass over the band:
+ *   out_dev (6, C) float64 rows = min mean, max mean, sum mean, min std, max std, sum std   (std rows 0 when std_dev NULL)
+ * mean_dev (C, plane) float64 and std_dev (C, plane) float32 are ct_hdr_merge_batch's outputs.  Deterministic (no
+ * atomics); min / max / sum combine over bands.  workspace_dev: ct_band_stats_workspace(channels) bytes, 8-byte aligned.
+ */
+int64_t ct_band_stats_workspace(int32_t channels);
+int ct_band_stats(const double *mean_dev, const float *std_dev, int32_t channels, int64_t plane, void *workspace_dev,
+                  int64_t workspace_bytes, double *out_dev, void *stream);
+
+/*
  * ct_dark_field_blur -- conditional_gaussian_blur(images, dark, threshold, 3, differentiable=True)
  * (clair_torch/common/general_functions.py:440-486) as compute_hdr_image (inference/hdr_merge.py:76-92,117-126) and
  * linearize_dataset_generator (inference/linearization.py:73-92,108-116) apply it, together with the per-sample

@@ -352,3 +352,34 @@ def test_codes_above_max_code_are_clamped_like_the_reference(dev, mode):
                                    interp=mode, std_mode="multiplier", std_value=0.05, max_code=4095.0)
         assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"max_code 4095 {mode} mean")
         assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"max_code 4095 {mode} std")
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 96), (3, 7, 9), (1, 5, 3), (4, 33, 64)])
+@pytest.mark.parametrize("with_std", [True, False])
+def test_band_statistics_match_torch_reductions(dev, shape, with_std):
+    """ct_band_stats (what configuration C5 gathers per band): min / max exactly, sums to float64 rounding; even and odd
+    plane sizes (vector and scalar loads), and bands combine to the whole image."""
+    from clair_torch_amd import ops
+    gen = torch.Generator().manual_seed(shape[1])
+    mean = (torch.rand(shape, generator=gen, dtype=torch.float64) * 3.0 - 1.0).to(dev)
+    std = torch.rand(shape, generator=gen, dtype=torch.float32).to(dev) if with_std else None
+    out = ops.band_stats(mean, std)
+    flat = mean.reshape(shape[0], -1)
+    ref = [flat.amin(dim=1), flat.amax(dim=1), flat.sum(dim=1)]
+    if with_std:
+        sflat = std.reshape(shape[0], -1)
+        ref += [sflat.amin(dim=1).double(), sflat.amax(dim=1).double(), sflat.double().sum(dim=1)]
+    else:
+        ref += [torch.zeros(shape[0], dtype=torch.float64, device=dev)] * 3
+    ref = torch.stack(ref)
+    assert out.shape == (6, shape[0])
+    assert torch.equal(out[[0, 1, 3, 4]], ref[[0, 1, 3, 4]])
+    assert torch.allclose(out[[2, 5]], ref[[2, 5]], rtol=1e-13, atol=1e-13)
+    assert torch.equal(out, ops.band_stats(mean, std))  # deterministic
+    if shape[1] >= 7:  # two row bands combine to the whole
+        a = ops.band_stats(mean[:, :3].contiguous(), std[:, :3].contiguous() if with_std else None)
+        b = ops.band_stats(mean[:, 3:].contiguous(), std[:, 3:].contiguous() if with_std else None)
+        comb = torch.stack([torch.minimum(a[0], b[0]), torch.maximum(a[1], b[1]), a[2] + b[2],
+                            torch.minimum(a[3], b[3]), torch.maximum(a[4], b[4]), a[5] + b[5]])
+        assert torch.equal(comb[[0, 1, 3, 4]], out[[0, 1, 3, 4]]) and torch.allclose(comb[[2, 5]], out[[2, 5]], rtol=1e-13, atol=1e-13)
+
