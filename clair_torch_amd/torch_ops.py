@@ -135,3 +135,15 @@ def pair_residual_lut_grad(stack: torch.Tensor, i_idx: torch.Tensor, j_idx: torc
 @pair_residual_lut_grad.register_fake
 def _(stack, i_idx, j_idx, ratio, coef, lut, interp, lower, upper, relative, max_code):
     return lut.new_empty(lut.shape, dtype=torch.float64)
+
+
+@torch.library.custom_op(f"{_LIB}::band_stats", mutates_args=())
+def band_stats(mean: torch.Tensor, std: Optional[torch.Tensor]) -> torch.Tensor:
+    """ct_band_stats: (6, C) float64 per-channel min / max / sum of a merged band's mean and std (configuration C5)."""
+    return ops.band_stats(mean, std)
+
+
+@band_stats.register_fake
+def _(mean, std):
+    return mean.new_empty((6, mean.shape[0]), dtype=torch.float64)
+

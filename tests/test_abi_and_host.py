@@ -503,7 +503,8 @@ def test_torch_library_ops_are_registered_with_schemas_and_fake_kernels():
     of CPU tensors."""
     from torch._subclasses.fake_tensor import FakeTensorMode
     from clair_torch_amd import torch_ops  # noqa: F401  (registers the ops)
-    names = ["icrf_forward", "icrf_backward", "hdr_merge", "linearize_std", "pair_residual_sums", "pair_residual_lut_grad"]
+    names = ["icrf_forward", "icrf_backward", "hdr_merge", "linearize_std", "pair_residual_sums", "pair_residual_lut_grad",
+             "band_stats"]
     for n in names:
         assert hasattr(torch.ops.clair_hip, n), n
     assert "Tensor? lut" in str(torch.ops.clair_hip.hdr_merge.default._schema)
@@ -524,5 +525,7 @@ def test_torch_library_ops_are_registered_with_schemas_and_fake_kernels():
                                                       torch.empty(7, dtype=torch.int64), torch.empty(7, dtype=torch.float64), lut,
                                                       "linear", 0.0, 1.0, True, False, "none", 0.0, 0.0, 1)
         assert tuple(sums.shape) == (7, 3, 5) and sums.dtype == torch.float64
+        st = torch.ops.clair_hip.band_stats(torch.empty((3, 8, 9), dtype=torch.float64), torch.empty((3, 8, 9)))
+        assert tuple(st.shape) == (6, 3) and st.dtype == torch.float64
     with pytest.raises(RuntimeError, match="MI355X"):
         torch.ops.clair_hip.icrf_forward(torch.zeros((1, 3, 4, 4)), torch.zeros((3, 16)), "linear")
