@@ -213,20 +213,43 @@ __device__ __forceinline__ void floor_index_bits(const float (&px)[V], float r, 
                      : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(r), "v"(magic));
     } else {
         static_assert(V == 1, "1 or 4 codes");
+        // (s_nop: gfx9 wants 2 wait states between two s_setreg writes of one hwreg; the assembler cannot see this block)
         asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
                      "v_fma_f32 %0, %1, %2, %3\n\t"
+                     "s_nop 1\n\t"
                      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
                      : "=&v"(t[0])
                      : "v"(px[0]), "v"(r), "v"(magic));
     }
 }
 
+// Two intervals per code (experiment: a second table with its own step): eight FMAs in one round-down block.
+template <int V>
+__device__ __forceinline__ void floor_index_bits2(const float (&px)[V], float r1, float r2, float magic, float (&t1)[V], float (&t2)[V])
+{
+    static_assert(V == 4, "packets of 4 codes");
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t"
+                 "v_fma_f32 %0, %8, %12, %14\n\t"
+                 "v_fma_f32 %1, %9, %12, %14\n\t"
+                 "v_fma_f32 %2, %10, %12, %14\n\t"
+                 "v_fma_f32 %3, %11, %12, %14\n\t"
+                 "v_fma_f32 %4, %8, %13, %14\n\t"
+                 "v_fma_f32 %5, %9, %13, %14\n\t"
+                 "v_fma_f32 %6, %10, %13, %14\n\t"
+                 "v_fma_f32 %7, %11, %13, %14\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t2[0]), "=&v"(t2[1]), "=&v"(t2[2]), "=&v"(t2[3])
+                 : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(r1), "v"(r2), "v"(magic));
+}
+
 // LDS byte address of table entry `interval` of the row at byte offset `row`: (bits(t) << 3) + (row - (0x4B400000 << 3))
 // mod 2^32, one v_lshl_add_u32; the row constant is formed once per tile.  (Tried and rejected: the same address by one
 // full-rate FMA against the inline integer constant 8 read as the denormal 8 * 2^-149 -- exact, but denormal operands
 // take a slow path: 0.879 against 0.856 ms on C2, profiles/r02_typed_load_ab.log.)
-__device__ __forceinline__ uint32_t lds_row_constant(int row_bytes) { return (uint32_t)row_bytes - (kFloorMagicBits << 3); }
-__device__ __forceinline__ uint32_t lds_entry_address(float t, uint32_t row_constant) { return (__float_as_uint(t) << 3) + row_constant; }
+template <int SHIFT = 3>
+__device__ __forceinline__ uint32_t lds_row_constant(int row_bytes) { return (uint32_t)row_bytes - (kFloorMagicBits << SHIFT); }
+template <int SHIFT = 3>
+__device__ __forceinline__ uint32_t lds_entry_address(float t, uint32_t row_constant) { return (__float_as_uint(t) << SHIFT) + row_constant; }
 
 // Code-domain LINEAR table for integer stacks whose LUT step is a whole number of codes: entry i = {g[i], (g[i+1]-g[i]) / step}
 // (the last interval has zero slope), f(code) = g[i] + slope * (code - i * step) with the offset formed exactly.

@@ -498,6 +498,19 @@ constexpr int kPivotDepth = CT_PIVOT_DEPTH;  // exposures in flight per thread
 constexpr float kPivotCondLimit = 8.0f;
 constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which the table keeps {g[i], S}: error bound 2^-25 * 64 = 2e-6  // sum |terms| / result above which a wavefront repeats the batch about the mean
 
+// Experiments with the weight evaluation (measured in profiles/r03_merge_weight_variants.md):
+//   0  shipped: one v_exp_f32 per sample
+//   1  fine linear weight table in LDS ((max_code + 1) >> CT_PIVOT_WT_SHIFT entries {Wa, Ws}, w = Wa + Ws * code): a second
+//      8-byte gather per sample instead of the squaring multiply and the transcendental
+//   2  16-byte LUT entries {A, S, W_i, D_i}: w = W_i * exp2(delta (D_i - m^2 delta)), delta = code - i * step, |exponent| <= 0.17,
+//      degree-4 polynomial: one ds_read_b128 instead of ds_read_b64, no transcendental, seven more full-rate instructions
+#ifndef CT_PIVOT_WEIGHT
+#define CT_PIVOT_WEIGHT 0
+#endif
+#ifndef CT_PIVOT_WT_SHIFT
+#define CT_PIVOT_WT_SHIFT 4
+#endif
+
 // The first-batch kernels (no state carried through the loop): 7 wavefronts per SIMD (72 VGPRs).  With the codes held as
 // four floats per packet instead of two packed dwords the 64-VGPR build spills 19 registers (1.24 ms); 7 and 6
 // wavefronts measure the same within 1 % (0.856 / 0.865 ms sustained, profiles/r02_typed_load_ab.log).  Raw-code
@@ -517,9 +530,13 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     constexpr bool kTyped = CT_PIVOT_TYPED_LOAD;  // codes arrive as floats from typed buffer loads
     using CodePk = std::conditional_t<kTyped, Packet<float, V>, Packet<T, V>>;
     const int C = a.channels, L = a.n_points, B = a.batch;
-    const int lut_bytes = kLut ? C * L * 8 : 0;
+    constexpr int kWV = (kLut && kGauss && kTyped && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;  // weight evaluation variant
+    constexpr int kEntryShift = kWV == 2 ? 4 : 3;
+    const int lut_bytes = kLut ? C * L * (1 << kEntryShift) : 0;
     float2 *expo = reinterpret_cast<float2 *>(lds + lut_bytes);  // per exposure {1 / t_n, chain factor of the y' term}
+    [[maybe_unused]] const uint32_t wt_base = (uint32_t)lut_bytes + 8u * (uint32_t)B;  // kWV == 1: the weight table
     const float kk = sqrtf(a.weight_scale * 1.4426950408889634f);
+    const float dk_mul = kk * a.inv_max_code, dk_add = -0.5f * kk;
     const float K = -2.0f * a.weight_scale;
     // y' = (df/dcode) max_code / t_n;  the loop forms (w s' df/dcode) * cq_n with cq_n = max_code (kk / K) / t_n
     const float max_code = kLut ? x.step * (float)(L - 1) : 1.0f;  // (no model: df/dcode * max_code = 1, folded)
@@ -551,7 +568,23 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             const float g0 = row[i], g1 = row[i + 1 < L ? i + 1 : L - 1];
             const float slope = (g1 - g0) / x.step;
             const float A = (float)((double)g0 - (double)slope * ((double)i * (double)x.step));
-            reinterpret_cast<float2 *>(lds)[k] = make_float2(rough ? g0 : A, slope);
+            if constexpr (kWV == 2) {
+                const double dki = (double)i * (double)x.step * (double)dk_mul + (double)dk_add;
+                reinterpret_cast<float4 *>(lds)[k] =
+                    make_float4(rough ? g0 : A, slope, (float)exp2(-dki * dki), (float)(-2.0 * dki * (double)dk_mul));
+            } else {
+                reinterpret_cast<float2 *>(lds)[k] = make_float2(rough ? g0 : A, slope);
+            }
+        }
+    }
+    if constexpr (kWV == 1) {
+        // entry j covers codes [j << s, (j + 1) << s): w = Wa + Ws * code, chord of exp2(-dk^2) over the interval
+        constexpr int s = CT_PIVOT_WT_SHIFT, nW = 65536 >> s;
+        for (int j = threadIdx.x; j < nW; j += kBlock) {
+            const double c0 = (double)(j << s), c1 = (double)((j + 1) << s);
+            const double d0 = c0 * (double)dk_mul + (double)dk_add, d1 = c1 * (double)dk_mul + (double)dk_add;
+            const double w0 = exp2(-d0 * d0), w1 = exp2(-d1 * d1), ws = (w1 - w0) / (c1 - c0);
+            *reinterpret_cast<float2 *>(lds + wt_base + 8u * (uint32_t)j) = make_float2((float)(w0 - ws * c0), (float)ws);
         }
     }
     for (int n = threadIdx.x; n < B; n += kBlock) {
@@ -563,7 +596,6 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     const bool finalize = a.flags & CT_MERGE_FINALIZE;
     const bool keep_state = a.mean_state != nullptr;
     const bool planar = a.tile.layout == CT_LAYOUT_NCHW;
-    const float dk_mul = kk * a.inv_max_code, dk_add = -0.5f * kk;
     float fsf = 1.0f;  // scale of the folded moments back to true units
     if constexpr (kGauss) fsf = K / kk;
     if constexpr (STD == CT_STD_CONSTANT) fsf *= a.std_value;
@@ -617,7 +649,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         [[maybe_unused]] uint32_t rowc[V];  // typed path: the row offset as the addend of lds_entry_address
         if constexpr (kTyped && kLut) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) rowc[e] = lds_row_constant(row_off[e]);
+            for (int e = 0; e < V; ++e) rowc[e] = lds_row_constant<kEntryShift>(row_off[e] << (kEntryShift - 3));
         }
 
         // loads are addressed as (wave-uniform exposure base) + (32-bit per-thread byte offset): no 64-bit VALU address math
@@ -638,7 +670,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 const float px = pk.v[e];
                 float lin = px * a.inv_max_code;
                 if constexpr (kLut) {
-                    const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address(tf[e], rowc[e]));
+                    const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address<kEntryShift>(tf[e], rowc[e]));
                     lin = __builtin_fmaf(g.y, rough ? __builtin_fmaf(tf[e] - floor_magic, -x.step, px) : px, g.x);
                 }
                 p[e] = lin * itp;
@@ -685,20 +717,37 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 float pxv[V], ga[V], gs[V];
                 [[maybe_unused]] float pxl[V];
                 [[maybe_unused]] float dkv[V], wv[V];
-                [[maybe_unused]] float tf[V];
+                [[maybe_unused]] float tf[V], tw[V], gw[V], gd[V];
                 if constexpr (kTyped) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) pxv[e] = pk.v[e];
-                    if constexpr (kLut) floor_index_bits<V>(pxv, index_rcp, floor_magic, tf);
+                    if constexpr (kLut && kWV == 1)
+                        floor_index_bits2<V>(pxv, index_rcp, 1.0f / (float)(1 << CT_PIVOT_WT_SHIFT), floor_magic, tf, tw);
+                    else if constexpr (kLut)
+                        floor_index_bits<V>(pxv, index_rcp, floor_magic, tf);
                 }
                 static_for<V>([&](auto ec) {  // stage A: the V table gathers and the V transcendentals, each issued together
                     constexpr int e = decltype(ec)::value;
                     if constexpr (kTyped) {
-                        if constexpr (kLut) {
+                        if constexpr (kLut && kWV == 2) {
+                            float4 g = *reinterpret_cast<const float4 *>(lds + lds_entry_address<4>(tf[e], rowc[e]));
+                            asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w));  // keep the ds_read_b128 whole
+                            ga[e] = g.x;
+                            gs[e] = g.y;
+                            gw[e] = g.z;
+                            gd[e] = g.w;
+                            pxl[e] = __builtin_fmaf(tf[e] - floor_magic, -x.step, pxv[e]);  // delta = code - i * step, exact
+                        } else if constexpr (kLut) {
                             const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address(tf[e], rowc[e]));
                             ga[e] = g.x;
                             gs[e] = g.y;
                             if constexpr (kRough) pxl[e] = __builtin_fmaf(tf[e] - floor_magic, -x.step, pxv[e]);  // code - i * step, exact
+                            if constexpr (kWV == 1) {
+                                const float2 wt = *reinterpret_cast<const float2 *>(
+                                    lds + lds_entry_address(tw[e], wt_base - (kFloorMagicBits << 3)));
+                                gw[e] = wt.x;
+                                gd[e] = wt.y;
+                            }
                         }
                     } else {
                     pxv[e] = code_to_float<T, V, e>(pk);
@@ -712,10 +761,27 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     }
                     if constexpr (kGauss) {
                         dkv[e] = __builtin_fmaf(pxv[e], dk_mul, dk_add);
-                        wv[e] = __builtin_amdgcn_exp2f(-dkv[e] * dkv[e]);
+                        if constexpr (kWV == 0) wv[e] = __builtin_amdgcn_exp2f(-dkv[e] * dkv[e]);
                     }
                 });
-                if constexpr (kGauss) {
+                if constexpr (kWV == 1) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) wv[e] = __builtin_fmaf(gd[e], pxv[e], gw[e]);
+                }
+                if constexpr (kWV == 2) {
+                    // exp2(v), v = delta (D_i - m^2 delta), |v| <= 0.17: 1 + v (c1 + v (c2 + v (c3 + v c4))), error < 2e-7
+                    const float m2 = dk_mul * dk_mul;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const float v = pxl[e] * __builtin_fmaf(pxl[e], -m2, gd[e]);
+                        float q = __builtin_fmaf(v, 0.009618129107628477f, 0.05550410866482158f);
+                        q = __builtin_fmaf(q, v, 0.2402265069591007f);
+                        q = __builtin_fmaf(q, v, 0.6931471805599453f);
+                        q = __builtin_fmaf(q, v, 1.0f);
+                        wv[e] = gw[e] * q;
+                    }
+                }
+                if constexpr (kGauss && kWV == 0) {
                     // pins the four v_exp_f32 ahead of the dependent arithmetic: measured 4 % faster than letting the
                     // scheduler sink each one next to its first use (profiles/r02_merge_ablation.md)
 #pragma unroll
@@ -917,7 +983,9 @@ static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
 {
     if (a.q_count == 0) return CT_OK;
     x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
-    const size_t lds = (INTERP == CT_INTERP_LINEAR ? (size_t)a.channels * a.n_points * 8 : 0) + 2 * sizeof(float) * (size_t)a.batch;
+    constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && CT_PIVOT_TYPED_LOAD && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;
+    const size_t lds = (INTERP == CT_INTERP_LINEAR ? (size_t)a.channels * a.n_points * (kWV == 2 ? 16 : 8) : 0) +
+                       2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
     return (a.flags & CT_MERGE_FIRST_BATCH) ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true>>(a, x, lds, stream)
                                             : launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false>>(a, x, lds, stream);

@@ -53,20 +53,24 @@ def gaussian_weight(image, scale=30.0):
     return torch.exp(-scale * (image - 0.5) ** 2)
 
 
-def merge_stack(vals, stds, exposures, lut, mode=LINEAR, use_gauss=True, partition=None):
+def merge_stack(vals, stds, exposures, lut, mode=LINEAR, use_gauss=True, partition=None, batches=None):
     """compute_hdr_image (clair_torch/inference/hdr_merge.py:61-155) without artefact corrections.
 
     vals (N,C,H,W) f32, stds same or None, exposures (N) f64.  ``partition`` lists the batch sizes.
     Streaming state follows WBOMean (clair_torch/common/statistics.py:64-109) incl. the per-batch detach.
     """
     n = vals.shape[0]
-    partition = [n] if partition is None else list(partition)
-    mean_a, w_a, variance, k = 0.0, 0.0, None, 0
-    for b in partition:
-        x = vals[k:k + b].clone().requires_grad_(stds is not None)
-        sd = None if stds is None else stds[k:k + b]
-        t = exposures[k:k + b].to(torch.float64).view(-1, 1, 1, 1)
-        k += b
+    if batches is None:   # ``partition`` = consecutive batch sizes; ``batches`` = explicit index lists (sorted per batch)
+        partition = [n] if partition is None else list(partition)
+        batches, k = [], 0
+        for b in partition:
+            batches.append(list(range(k, k + b)))
+            k += b
+    mean_a, w_a, variance = 0.0, 0.0, None
+    for idx in batches:
+        x = vals[idx].clone().requires_grad_(stds is not None)
+        sd = None if stds is None else stds[idx]
+        t = exposures[idx].to(torch.float64).view(-1, 1, 1, 1)
         wts = gaussian_weight(x) if use_gauss else torch.ones_like(x)
         with torch.set_grad_enabled(stds is not None):
             y = (icrf_forward(x, lut, mode) if lut is not None else x) / t
@@ -79,6 +83,117 @@ def merge_stack(vals, stds, exposures, lut, mode=LINEAR, use_gauss=True, partiti
             upd = ((g * sd) ** 2).sum(dim=0, keepdim=True)
             variance = upd if variance is None else variance + upd
         mean_a, w_a = mean.detach(), w_t.detach()
+    return mean_a.squeeze(0), (None if variance is None else torch.sqrt(variance.squeeze(0)))
+
+
+# ---- float32-order emulation of the reference's backward (no autograd) ---------------------------------------------
+# What torch.autograd.grad computes at hdr_merge.py:107-113, written out operation by operation in the order PyTorch's
+# engine executes the nodes (highest sequence number first; gradients arriving at one tensor are added in arrival order)
+# and in the dtype of each forward operation (float32 image-side, float64 once the exposure times enter).  With the same
+# exp() it reproduces the reference's recorded uncertainties BIT FOR BIT (tests/test_oracle_golden.py), so it serves as
+#   * the specification of the kernels' "reference order" paths (CATMULL derivative: ct_device.hpp catmull_backward_ref;
+#     the exact-order merge pass: ct_merge.hip), and
+#   * the instrument that tells rounding noise of the reference itself from error of the build: replacing ``exp`` by a
+#     correctly rounded one (torch's CPU exp is Sleef's 1-ULP expf: 1.1 % of its results differ from correct rounding)
+#     moves the reference's own CATMULL uncertainty by up to 1.1e-5 element-wise on the uint16 fixtures.
+def icrf_forward_backward_reference_order(x, lut, mode):
+    """ICRFModelBase.forward (clair_torch/models/base.py:135-226) and a closure G -> d(sum G * out)/dx evaluated in
+    autograd's float32 operation order.  x (N,C,H,W) float32.  LOOKUP has no gradient (closure None)."""
+    n, c, h, w = x.shape
+    size = lut.shape[1]
+    top = float(size - 1)
+    if mode == LOOKUP:
+        return icrf_forward(x, lut, mode), None
+    rows = torch.arange(c).repeat(n * h * w)
+
+    def take(ix):
+        return lut[rows, ix.reshape(-1)].reshape(n, c, h, w)
+
+    sraw = x * top
+    s = sraw.clamp(0, top)
+    smask = ((sraw >= 0) & (sraw <= top)).to(x.dtype)                # ClampBackward1
+    i0 = s.floor().long()
+    if mode == LINEAR:                                               # base.py:160-182
+        fr = s - i0.float()
+        g0, g1 = take(i0), take((i0 + 1).clamp(0, size - 1))
+        out = g0 * (1.0 - fr) + g1 * fr
+
+        def backward(grad):
+            # nodes: rsub (1 - fr), mul g0 *, mul g1 *, add.  Engine: add, g1 * fr (fr receives G g1 first), g0 * (1 - fr),
+            # rsub (fr receives -(G g0) second)
+            gfr = (grad * g1) + (-(grad * g0))
+            return (gfr * smask) * top
+
+        return out, backward
+    if mode == CATMULL:                                              # base.py:184-226
+        traw = s - i0.float()
+        t = traw.clamp(0, 1)
+        tmask = ((traw >= 0) & (traw <= 1)).to(x.dtype)
+        t2 = t * t
+        t3 = t2 * t
+        basis = (-0.5 * t3 + t2 - 0.5 * t, 1.5 * t3 - 2.5 * t2 + 1.0, -1.5 * t3 + 2.0 * t2 + 0.5 * t, 0.5 * t3 - 0.5 * t2)
+        taps = [take((i0 + k).clamp(0, size - 1)) for k in (-1, 0, 1, 2)]
+        out = torch.stack([b * g for b, g in zip(basis, taps)], dim=0).sum(dim=0)
+
+        def backward(grad):
+            # the four products w_k * g_k run first (latest nodes), then the nodes of w3, w2, w1, w0 in that order; each
+            # feeds t3, t2 and t, whose buffers add in arrival order; t3 = t2 * t and t2 = t * t run last
+            g0, g1, g2, g3 = [grad * g for g in taps]
+            a3 = ((0.5 * g3 - 1.5 * g2) + 1.5 * g1) - 0.5 * g0                          # d / d t3
+            a2 = ((((-(0.5 * g3)) + 2.0 * g2) - 2.5 * g1) + g0) + a3 * t                # d / d t2 (last arrival: via t3)
+            at = (((0.5 * g2 - 0.5 * g0) + a3 * t2) + a2 * t) + a2 * t                  # d / d t  (t * t feeds t twice)
+            return ((at * tmask) * smask) * top
+
+        return out, backward
+    raise ValueError(f"Unknown interpolation mode {mode}")
+
+
+def merge_stack_reference_order(vals, stds, exposures, lut, mode=LINEAR, use_gauss=True, batches=None, exp=torch.exp):
+    """compute_hdr_image (clair_torch/inference/hdr_merge.py:61-155) with the backward of :107-113 written out in
+    autograd's order.  ``batches``: list of index lists (each already sorted by exposure as custom_collate does) or None
+    for one batch.  ``exp``: the exponential used by gaussian_value_weights (default torch.exp = what the reference runs)."""
+    n = vals.shape[0]
+    batches = [list(range(n))] if batches is None else batches
+    f32, f64 = torch.float32, torch.float64
+    mean_a = w_a = variance = None
+    for idx in batches:
+        x = vals[idx]
+        sd = None if stds is None else stds[idx]
+        t = exposures[idx].to(f64).view(-1, 1, 1, 1)
+        xm = x - 0.5
+        wts = exp(-30.0 * xm ** 2) if use_gauss else torch.ones_like(x)             # losses.py:205 / hdr_merge.py:95
+        if lut is None:
+            lin, backward = x, (lambda grad: grad)
+        else:
+            lin, backward = icrf_forward_backward_reference_order(x, lut, mode)
+        y = lin / t                                                                   # float64 from here on
+        w_b = wts.sum(dim=0, keepdim=True)                                            # statistics.py:78-80 (float32)
+        swy = (wts * y).sum(dim=0, keepdim=True)
+        d = w_b + 1e-6
+        m_b = swy / d
+        first = mean_a is None
+        w_t = w_b if first else w_a + w_b                                             # statistics.py:103 (0.0 + W_B first)
+        frac = w_b / w_t                                                              # float32
+        diff = m_b if first else m_b - mean_a
+        mean = frac * diff if first else mean_a + frac * diff
+        if sd is not None:
+            g_frac = diff.to(f32)                                                     # d mean / d frac, cast at the float32 tensor
+            g_swy = frac.to(f64) / d.to(f64)
+            g_d = (-frac.to(f64) * ((swy / d) / d)).to(f32)                           # DivBackward0: -grad * ((self / other) / other)
+            g_wb = g_frac / w_t                                                       # arrival 1: W_B / W, self
+            g_wb = g_wb + (-g_frac * ((w_b / w_t) / w_t))                             # arrival 2: through W = W_A + W_B
+            g_wb = g_wb + g_d                                                         # arrival 3: through W_B + 1e-6
+            g_lin = ((g_swy * wts) / t).to(f32)                                       # into the model's output
+            g_x = None if backward is None else backward(g_lin)                       # model nodes run before the weight nodes
+            if use_gauss:
+                g_w = (g_swy * y).to(f32) + g_wb                                      # mul first, then the expanded sum
+                g_a = ((g_w * wts) * -30.0) * (2.0 * xm)                              # exp, * (-scale), pow 2 backward
+                g_x = g_a if g_x is None else g_x + g_a
+            if g_x is None:
+                raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
+            upd = ((g_x * sd) ** 2).sum(dim=0, keepdim=True)
+            variance = upd if variance is None else variance + upd
+        mean_a, w_a = mean, w_t
     return mean_a.squeeze(0), (None if variance is None else torch.sqrt(variance.squeeze(0)))
 
 

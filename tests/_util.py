@@ -7,6 +7,16 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PARTITIONS = {"8": [8], "44": [4, 4], "332": [3, 3, 2]}
 
 
+def sampler_batches(sampler, exposures):
+    """Batches of a recorded batch_sampler (rows padded with -1), each sorted by exposure time like custom_collate
+    (clair_torch/datasets/collate.py:23; Python's sort is stable)."""
+    out = []
+    for row in np.asarray(sampler):
+        idx = [int(i) for i in row if i >= 0]
+        out.append(sorted(idx, key=lambda i: exposures[i]))
+    return out
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, f"{name}.npz"))
 

@@ -191,6 +191,58 @@ def gen_merge(out):
         out["merge_lookup_nograd_raises"] = np.asarray(1)
 
 
+SHUFFLED_SAMPLERS = {
+    # the scripts' default is shuffle: true (scripts/config.yaml:18); custom_collate sorts only WITHIN a batch
+    # (datasets/collate.py:23) and the variance depends on the batch order (inference/hdr_merge.py:128)
+    "s323": [[6, 1, 4], [7, 0], [3, 5, 2]],
+    "long3": [[7, 5, 6], [2, 0, 1], [4, 3]],          # first batch = the three longest (most saturated) exposures
+    "perm4": None,                                     # filled below: torch.randperm(8) in batches of 4 (shuffle=True, batch_size=4)
+}
+
+
+def gen_merge_shuffled(out):
+    """compute_hdr_image with non-monotone batch composition (VERDICT r2 missing #2)."""
+    gen = torch.Generator().manual_seed(212)
+    lut = lut_rows((2.2, 2.4, 2.6))
+    out["shuf_lut"] = lut.numpy()
+    n, c, h, w = 8, 3, 16, 16
+    exposures = [0.001 * 2.0 ** k for k in range(n)]
+    out["shuf_exposures"] = np.asarray(exposures, dtype=np.float64)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(7)).tolist()
+    samplers = dict(SHUFFLED_SAMPLERS)
+    samplers["perm4"] = [perm[:4], perm[4:]]
+    for name, batches in samplers.items():
+        flat = np.full((len(batches), n), -1, dtype=np.int64)
+        for k, bt in enumerate(batches):
+            flat[k, :len(bt)] = bt
+        out[f"shuf_sampler_{name}"] = flat
+    cases = []
+    for bits, maxcode in ((8, 255), (16, 65535)):
+        codes = synthetic_codes(gen, n, c, h, w, maxcode, exposures)
+        out[f"shuf_u{bits}_codes"] = codes.numpy().astype(np.uint16 if bits == 16 else np.uint8)
+        vals = [normalize_tensor(codes[i].float(), max_val=maxcode, min_val=0) for i in range(n)]
+        explicit = make_stds(vals, "explicit", gen)
+        out[f"shuf_u{bits}_explicit_std"] = torch.stack(explicit).numpy()
+        for mname in ("linear", "lookup", "catmull", "nomodel"):
+            for wname in ("none", "gauss"):
+                if wname == "none" and mname != "linear":
+                    continue
+                for sname in ("constant", "multiplier", "explicit"):
+                    for pname, batches in samplers.items():
+                        stds = explicit if sname == "explicit" else make_stds(vals, sname, gen)
+                        ds = MemoryStack([v.clone() for v in vals], stds, exposures)
+                        model = None if mname == "nomodel" else ICRFModelDirect(
+                            icrf=lut.clone(), interpolation_mode=MODES[mname])
+                        wf = None if wname == "none" else ref_losses.gaussian_value_weights
+                        loader = DataLoader(ds, batch_sampler=[list(bt) for bt in batches], collate_fn=custom_collate)
+                        mean, std = compute_hdr_image(loader, "cpu", model, weight_fn=wf)
+                        key = f"shuf_u{bits}_{mname}_{wname}_{sname}_{pname}"
+                        out[key + "_mean"] = mean.detach().numpy()
+                        out[key + "_std"] = std.detach().numpy()
+                        cases.append(key)
+    out["shuf_cases"] = np.asarray(cases)
+
+
 def gen_merge_c1(out):
     """BASELINE config C1 shape: 8 x 256x256x3 uint8, through the reference on CPU (batch 4 and 8)."""
     gen = torch.Generator().manual_seed(1234 + 1)
@@ -487,9 +539,13 @@ def gen_video_stats(out):
 
 
 def main():
-    for name, fn in (("model_forward", gen_model_forward), ("merge", gen_merge), ("merge_c1", gen_merge_c1),
+    only = set(sys.argv[1:])   # e.g. `make_golden.py merge_shuffled` regenerates one file
+    for name, fn in (("model_forward", gen_model_forward), ("merge", gen_merge), ("merge_shuffled", gen_merge_shuffled),
+                     ("merge_c1", gen_merge_c1),
                      ("linearize", gen_linearize), ("training", gen_training), ("helpers", gen_helpers),
                      ("flatfield", gen_flatfield), ("video_stats", gen_video_stats)):
+        if only and name not in only:
+            continue
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

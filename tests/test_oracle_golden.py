@@ -9,7 +9,7 @@ import torch
 
 from oracle import ct_oracle as oc
 from oracle import eager_torch as oe
-from _util import PARTITIONS, assert_parity, golden, std_for
+from _util import PARTITIONS, assert_parity, golden, sampler_batches, std_for
 
 MODES = ("lookup", "linear", "catmull")
 
@@ -79,6 +79,86 @@ def test_merge_eager_oracle_vs_golden():
         if sd is not None:
             assert std.dtype == torch.float32
             assert_parity(std.numpy(), g[key + "_std"], rtol=1e-6, norm_tol=1e-6, what=key + " std")
+
+
+def _batches_of(part):
+    out, k = [], 0
+    for b in part:
+        out.append(list(range(k, k + b)))
+        k += b
+    return out
+
+
+def _shuffled_inputs(g, key):
+    _, ub, mname, wname, sname, pname = key.split("_")
+    x = oc.normalize_codes(g[f"shuf_{ub}_codes"])
+    sd = std_for(sname, x, g[f"shuf_{ub}_explicit_std"])
+    lut = None if mname == "nomodel" else g["shuf_lut"]
+    batches = sampler_batches(g[f"shuf_sampler_{pname}"], g["shuf_exposures"])
+    return x, sd, lut, ("linear" if mname == "nomodel" else mname), wname == "gauss", batches
+
+
+def test_merge_reference_order_emulation_is_bit_exact():
+    """oracle/eager_torch.merge_stack_reference_order spells the reference's autograd backward out operation by operation
+    (no autograd).  It must reproduce EVERY recorded mean and uncertainty bit for bit -- contiguous and shuffled batch
+    composition, all modes -- which pins the operation order the kernels' reference-order paths follow."""
+    n = 0
+    for name, prefix, inputs in (("merge", "merge", _merge_inputs), ("merge_shuffled", "shuf", _shuffled_inputs)):
+        g = golden(name)
+        t = torch.from_numpy(g[f"{prefix}_exposures"])
+        for key in [str(k) for k in g[f"{prefix}_cases"]]:
+            x, sd, lut, mode, gauss, part = inputs(g, key)
+            batches = part if prefix == "shuf" else _batches_of(part)
+            mean, std = oe.merge_stack_reference_order(torch.from_numpy(x), None if sd is None else torch.from_numpy(np.ascontiguousarray(sd)),
+                                                       t, None if lut is None else torch.from_numpy(lut), mode, gauss, batches)
+            assert np.array_equal(mean.numpy(), g[key + "_mean"]), key
+            if sd is not None:
+                assert np.array_equal(std.numpy(), g[key + "_std"]), key
+                n += 1
+    assert n > 150
+
+
+def test_reference_uncertainty_depends_on_the_last_bit_of_exp():
+    """How much of a residual against the golden vectors is the reference's OWN rounding: the same emulation with a
+    correctly rounded exp (torch's CPU exp is Sleef's 1-ULP expf; about 1 % of its results are not the correctly rounded
+    ones) moves the reference's uncertainty by up to 1.1e-5 element-wise for CATMULL on uint16 data (the float32 chain
+    G * g_k through the cubic basis cancels ~100x and amplifies a last-bit change of the weight) and by < 3e-6 for the
+    other modes.  An implementation whose exp differs from Sleef's in the last bit cannot be closer than this."""
+    g = golden("merge")
+    t = torch.from_numpy(g["merge_exposures"])
+    exact_exp = lambda v: torch.exp(v.double()).float()   # noqa: E731
+    worst = {}
+    for key in [str(k) for k in g["merge_cases"]]:
+        _, ub, mname, wname, sname, pname = key.split("_")
+        if sname == "none" or wname != "gauss":
+            continue
+        x, sd, lut, mode, gauss, part = _merge_inputs(g, key)
+        _, std = oe.merge_stack_reference_order(torch.from_numpy(x), torch.from_numpy(np.ascontiguousarray(sd)), t,
+                                                None if lut is None else torch.from_numpy(lut), mode, True, _batches_of(part),
+                                                exp=exact_exp)
+        ref = g[key + "_std"]
+        med = np.median(np.abs(ref))
+        el = float(np.max(np.abs(std.numpy().astype(np.float64) - ref) / (np.abs(ref) + med)))
+        worst[(mname, ub)] = max(worst.get((mname, ub), 0.0), el)
+    assert worst[("catmull", "u16")] > 5e-6            # the sensitivity is real ...
+    assert max(worst.values()) < 1.2e-5                # ... and bounds what parity against these vectors can mean
+    assert max(v for k, v in worst.items() if k != ("catmull", "u16")) < 3e-6
+
+
+def test_merge_shuffled_batches_c_oracle_vs_golden():
+    """Non-monotone batch composition (shuffle: true is the scripts' default; batches are sorted only internally)."""
+    g = golden("merge_shuffled")
+    t = g["shuf_exposures"]
+    keys = [str(k) for k in g["shuf_cases"]]
+    assert len(keys) >= 90
+    for key in keys:
+        x, sd, lut, mode, gauss, batches = _shuffled_inputs(g, key)
+        order = [i for b in batches for i in b]
+        mean, std = oc.hdr_merge(np.ascontiguousarray(x[order]), np.ascontiguousarray(sd[order]), np.ascontiguousarray(t[order]),
+                                 lut, mode, gauss, [len(b) for b in batches])
+        mname = key.split("_")[2]
+        assert_parity(mean, g[key + "_mean"], rtol=1e-6, norm_tol=1e-6, what=key + " mean")
+        assert_parity(std, g[key + "_std"], norm_tol=NORM_TOL[mname], elem_tol=ELEM_TOL[mname], what=key + " std")
 
 
 def test_merge_lookup_without_weight_raises():

@@ -169,7 +169,8 @@ int main(int argc, char **argv)
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double bytes = (double)S * 2 + (double)Q * 12;
-    for (int mode = only ? 1 : 0; mode < (only ? 2 : 3); ++mode) {
+    const int mode_only = getenv("MERGE_BENCH_MODE") ? atoi(getenv("MERGE_BENCH_MODE")) : 1;  // data set of a filtered run
+    for (int mode = only ? mode_only : 0; mode < (only ? mode_only + 1 : 3); ++mode) {
         hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, stack, S, 12345u, mode, Q);
         CK(hipDeviceSynchronize());
         printf("== data: %s, N=%d %dx%d, algorithmic bytes %.3f GB ==\n", mode == 0 ? "uniform random codes" : mode == 1 ? "gamma-2.2 scene, independent pixels" : "gamma-2.2 scene, smooth ramp", N, H, Wd, bytes / 1e9);
