@@ -17,9 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libclair_hip.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")   # per-source objects (git-ignored), so one edited kernel recompiles alone
-SOURCES = ["ct_merge.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_flatfield.hip", "ct_stats.hip", "ct_darkfield.hip", "ct_bandstats.hip",
+SOURCES = ["ct_merge.hip", "ct_merge_exact.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_flatfield.hip", "ct_stats.hip", "ct_darkfield.hip", "ct_bandstats.hip",
            "ct_api.cpp"]
-HEADERS = ["ct_device.hpp", os.path.join("..", "..", "include", "clair_hip.h")]
+HEADERS = ["ct_device.hpp", "ct_merge.hpp", os.path.join("..", "..", "include", "clair_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 

@@ -68,6 +68,21 @@ __device__ __forceinline__ void stage_lut(char *lds, const float *__restrict__ l
     }
 }
 
+// d(G * result)/dt of the Catmull-Rom sum exactly as PyTorch's autograd evaluates the backward of
+// clair_torch/models/base.py:199-224: the four products w_k * g_k run first (G_k = G * g_k), then the nodes of w3, w2, w1,
+// w0; gradients meeting at t3, t2 and t are added in arrival order; t3 = t2 * t and t2 = t * t run last (t * t feeds t
+// twice).  Un-fused float32 (-ffp-contract=off).  oracle/eager_torch.icrf_forward_backward_reference_order is the same
+// sequence on the CPU and reproduces the reference's recorded uncertainties bit for bit (tests/test_oracle_golden.py).
+// The float32 sum cancels ~100x, so any other order (e.g. the better conditioned closed form below) differs from the
+// reference by up to 1e-4 on single samples.
+__device__ __forceinline__ float catmull_backward_ref(float t, float t2, const float4 g, float G)
+{
+    const float g0 = G * g.x, g1 = G * g.y, g2 = G * g.z, g3 = G * g.w;
+    const float a3 = ((0.5f * g3 - 1.5f * g2) + 1.5f * g1) - 0.5f * g0;
+    const float a2 = (((2.0f * g2 - 0.5f * g3) - 2.5f * g1) + g0) + a3 * t;
+    return (((0.5f * g2 - 0.5f * g0) + a3 * t2) + a2 * t) + a2 * t;
+}
+
 // One sample through the staged LUT.
 //   EXACT   : reproduce the reference's float32 operation order bit for bit (linearize path);
 //             otherwise the lerp is a single FMA (merge path, 1e-5 tolerance).
@@ -125,16 +140,43 @@ __device__ __forceinline__ float icrf_sample(float x, const char *row_lds, float
             r = r + w1 * g.y;
             r = r + w2 * g.z;
             r = r + w3 * g.w;
-            // derivative of the basis in t, chained through s = x * (L-1)
-            const float d0 = __builtin_fmaf(__builtin_fmaf(-1.5f, t, 2.0f), t, -0.5f);
-            const float d1 = __builtin_fmaf(4.5f, t, -5.0f) * t;
-            const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
-            const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
-            // sum (g_k - g_1) d_k: the d_k sum to zero, subtracting g_1 removes the ~100x cancellation
-            const float acc = __builtin_fmaf(d0, g.x - g.y, __builtin_fmaf(d2, g.z - g.y, d3 * (g.w - g.y)));
-            (void)d1;
-            dfdx = acc * top * pass;
+            if constexpr (EXACT) {
+                // the reference's own float32 backward with unit upstream gradient (linearization.py:100-105)
+                dfdx = (catmull_backward_ref(t, t2, g, 1.0f) * pass) * top;
+            } else {
+                // derivative of the basis in t, chained through s = x * (L-1)
+                const float d0 = __builtin_fmaf(__builtin_fmaf(-1.5f, t, 2.0f), t, -0.5f);
+                const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
+                const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
+                // sum (g_k - g_1) d_k: the d_k sum to zero, subtracting g_1 removes the ~100x cancellation
+                const float acc = __builtin_fmaf(d0, g.x - g.y, __builtin_fmaf(d2, g.z - g.y, d3 * (g.w - g.y)));
+                dfdx = acc * top * pass;
+            }
             return r;
+        }
+    }
+}
+
+// d(G * f(x))/dx for float32 x in autograd's operation order (the upstream gradient multiplies the LUT taps FIRST):
+// what ICRFModelBase.forward's backward hands to the image (clair_torch/models/base.py:160-226), bit for bit.
+template <int INTERP>
+__device__ __forceinline__ float icrf_grad_reference_order(float x, const char *row_lds, float top, float G)
+{
+    if constexpr (INTERP == CT_INTERP_LOOKUP || INTERP == CT_INTERP_NONE) {
+        return INTERP == CT_INTERP_NONE ? G : 0.0f;
+    } else {
+        const float sraw = x * top;
+        const float s = fminf(fmaxf(sraw, 0.0f), top);
+        const float pass = (sraw >= 0.0f && sraw <= top) ? 1.0f : 0.0f;
+        const float fl = floorf(s);
+        const int i0 = (int)fl;
+        const float t = s - fl;
+        if constexpr (INTERP == CT_INTERP_LINEAR) {
+            const float2 g = reinterpret_cast<const float2 *>(row_lds)[i0];
+            return ((G * g.y - G * g.x) * pass) * top;  // fr receives G g1 first, then -(G g0)
+        } else {
+            const float4 g = reinterpret_cast<const float4 *>(row_lds)[i0];
+            return (catmull_backward_ref(t, t * t, g, G) * pass) * top;
         }
     }
 }

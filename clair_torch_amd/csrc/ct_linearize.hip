@@ -238,9 +238,7 @@ __global__ __launch_bounds__(kBlock) void linearize_bwd_kernel(const BwdArgs a)
         for (uint32_t n = blockIdx.y; n < a.n_images; n += gridDim.y) {
             const int64_t off = (int64_t)n * a.image_stride + q;
             const float x = a.x[off], go = a.grad_out[off];
-            float dfdx;
-            (void)icrf_sample<INTERP, true, false>(x, row_lds, top, dfdx);
-            if (a.grad_x) a.grad_x[off] = go * dfdx;
+            if (a.grad_x) a.grad_x[off] = icrf_grad_reference_order<INTERP>(x, row_lds, top, go);
             if (want_lut) {
                 if constexpr (INTERP == CT_INTERP_LOOKUP) {
                     float r = rintf(x * top);

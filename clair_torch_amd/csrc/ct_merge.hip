@@ -21,40 +21,10 @@
 //
 // Roofline: HBM.  Algorithmic bytes per output element = B * sizeof(T) (+ 4 B with an explicit std stack)
 // read + 12 written (float64 mean + float32 std).  No MFMA: this is a gather/reduce, not a contraction.
-#include "ct_device.hpp"
+#include "ct_merge.hpp"
 #include <type_traits>
 
 namespace ct {
-
-#define GLOBAL_AS __attribute__((address_space(1)))  // global memory (keeps laundered addresses off the flat path)
-
-struct MergeArgs {
-    const void *stack;
-    const float *std_stack;
-    const double *exposure;
-    const float *lut;
-    double *mean_state;
-    float *sumw_state;
-    float *var_state;
-    void *mean_out;
-    float *std_out;
-    int64_t image_stride;  // elements
-    uint32_t q_begin;      // first local element handled by this launch
-    uint32_t q_count;      // number of local elements handled by this launch (multiple of V)
-    TileMap tile;
-    int32_t batch, channels, n_points;
-    NormConst norm;       // code -> pixel (un-folded path)
-    NormConst index;      // code -> LUT coordinate s = u * (L-1) / max_code (folded path)
-    float inv_max_code;   // 1 / max_code (1 for float input)
-    float std_value;
-    float weight_scale;   // Gaussian scale (30)
-    uint32_t flags;
-};
-
-template <typename T, int V>
-struct alignas(sizeof(T) * V) Packet {
-    T v[V];
-};
 
 // Arithmetic of one sample, written so that every constant factor is folded out of the loop:
 //   dk  = kk (x - 1/2),  kk = sqrt(scale log2 e)          w = exp2(-dk^2)            (= exp(-scale (x-1/2)^2))
@@ -1169,10 +1139,22 @@ static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_poin
     return true;
 }
 
+// CATMULL with uncertainties follows the reference's float32 autograd order by default (ct_merge_exact.hip: the closed form
+// differs from the reference by the reference's own cancellation noise, up to 2e-5); CT_MERGE_REFERENCE_ORDER asks for
+// that path in any mode, CT_MERGE_CLOSED_FORM keeps the fast closed-form kernels for CATMULL too.
+static bool merge_uses_reference_order(int interp, int std_mode, uint32_t flags)
+{
+    if (flags & CT_MERGE_REFERENCE_ORDER) return true;
+    return interp == CT_INTERP_CATMULL && std_mode != CT_STD_NONE && !(flags & (CT_MERGE_CLOSED_FORM | CT_MERGE_F64_MOMENTS));
+}
+
 // Which kernel ct_hdr_merge_batch dispatches for these arguments (bench.py records it next to its numbers).
 extern "C" const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, int32_t interp, int32_t n_points,
                                                 uint32_t flags)
 {
+    // (std mode unknown here: CT_MERGE_STD_HINT in flags says uncertainties are propagated)
+    if (merge_uses_reference_order(interp, (flags & CT_MERGE_STD_HINT) ? CT_STD_CONSTANT : CT_STD_NONE, flags))
+        return "ct::merge_reference_order_kernel (the reference's float32 autograd order, two passes, float64 exp and divisions)";
     ct::PivotArgs px{};
     if (pivot_eligible(dtype, max_code, interp, interp == CT_INTERP_NONE ? 2 : n_points, flags, &px))
         return (flags & CT_MERGE_FIRST_BATCH)
@@ -1239,6 +1221,10 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
     a.inv_max_code = 1.0f;
     a.flags = flags;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (merge_uses_reference_order(interp, std_mode, flags)) {
+        if (dtype != CT_DTYPE_F32 && ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+        return merge_reference_order(a, dtype, (uint32_t)Ql, interp, weight_mode, std_mode, s);
+    }
     switch (dtype) {
         case CT_DTYPE_U8:
         case CT_DTYPE_U16: {

@@ -1,0 +1,43 @@
+// ct_merge.hpp -- argument block and packet type shared by the merge kernels (ct_merge.hip, ct_merge_exact.hip).
+#pragma once
+#include "ct_device.hpp"
+
+namespace ct {
+
+#define GLOBAL_AS __attribute__((address_space(1)))  // global memory (keeps laundered addresses off the flat path)
+
+struct MergeArgs {
+    const void *stack;
+    const float *std_stack;
+    const double *exposure;
+    const float *lut;
+    double *mean_state;
+    float *sumw_state;
+    float *var_state;
+    void *mean_out;
+    float *std_out;
+    int64_t image_stride;  // elements
+    uint32_t q_begin;      // first local element handled by this launch
+    uint32_t q_count;      // number of local elements handled by this launch (multiple of V)
+    TileMap tile;
+    int32_t batch, channels, n_points;
+    NormConst norm;       // code -> pixel (un-folded path)
+    NormConst index;      // code -> LUT coordinate s = u * (L-1) / max_code (folded path)
+    float inv_max_code;   // 1 / max_code (1 for float input)
+    float std_value;
+    float weight_scale;   // Gaussian scale (30)
+    uint32_t flags;
+};
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Packet {
+    T v[V];
+};
+
+
+// ct_merge_exact.hip: the merge with the reference's float32 autograd order (two passes over the batch); `q_count` elements
+// from `q_begin`, dispatched on dtype / interpolation / weight / std mode.  Returns a CT_* status.
+int merge_reference_order(const MergeArgs &a, int dtype, uint32_t q_total, int interp, int weight_mode, int std_mode,
+                          hipStream_t stream);
+
+}  // namespace ct

@@ -97,7 +97,7 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
                     std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                     max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
                     tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw",
-                    force_f64_moments: bool = False):
+                    force_f64_moments: bool = False, reference_order: Optional[bool] = None):
     """One batch of the HDR merge (ct_hdr_merge_batch).  Returns (mean, std|None) when ``finalize`` else None.
 
     stack (B,C,H,W) uint8/uint16 codes (give ``max_code``) or float32 pixels; exposures (B) any float dtype.
@@ -106,6 +106,9 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
     outputs stay planar (C,H,W).
     ``force_f64_moments`` (diagnostic, CT_MERGE_F64_MOMENTS): keep the float64-moment kernel where the pivoted
     float32 one would run (tests compare the two).
+    ``reference_order``: True = evaluate the uncertainty in the reference's own float32 autograd order
+    (CT_MERGE_REFERENCE_ORDER: two passes, slower, reproduces the reference's rounding); False = closed-form kernels in
+    every mode (CT_MERGE_CLOSED_FORM); None = the library's default (reference order for CATMULL with uncertainties only).
     """
     _check_stack(stack)
     b = stack.shape[0]
@@ -142,6 +145,8 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
     flags = (nv.MERGE_FIRST_BATCH if first else 0) | (nv.MERGE_FINALIZE if finalize else 0)
     if force_f64_moments:
         flags |= nv.MERGE_F64_MOMENTS
+    if reference_order is not None:
+        flags |= nv.MERGE_REFERENCE_ORDER if reference_order else nv.MERGE_CLOSED_FORM
     if mean_dtype == torch.float32:
         flags |= nv.MERGE_MEAN_OUT_F32
     elif mean_dtype != torch.float64:
