@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
             "ct_pair_residual_bwd", "ct_pair_residual_bwd_workspace", "ct_abi_version", "ct_error_string"} <= declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in clair_hip.h but not exported"
-    assert lib.ct_abi_version() == 2
+    assert lib.ct_abi_version() == 3
     assert lib.ct_error_string(0) == b"ok" and b"gradient" in lib.ct_error_string(-4)
 
 
