@@ -24,7 +24,7 @@ EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linear
            "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_pair_residual_bwd_workspace", "ct_flatfield_sums",
            "ct_flatfield_apply", "ct_video_stats_batch", "ct_dark_field_blur", "ct_hdr_merge_kernel_name",
            "ct_merge_set_retry_counter", "ct_norm_constants", "ct_index_constants", "ct_pivot_index_constants",
-           "ct_pivot_floor_constants", "ct_band_stats", "ct_band_stats_workspace")
+           "ct_pivot_floor_constants", "ct_pivot_interval_constants", "ct_band_stats", "ct_band_stats_workspace")
 
 
 class Geometry(ctypes.Structure):

@@ -181,3 +181,70 @@ extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp
     *rcp_step = cached_rcp;
     return cached_rc;
 }
+
+// Table addressing of ct::merge_pivot_kernel for ANY (max_code, L): entry(u) = min(floor(u * scale), last) by one FMA that
+// rounds toward minus infinity on the code held as a float, with scale ~ (L-1) / max_code (LINEAR: entry = interpolation
+// interval) or 2 (L-1) / max_code (LOOKUP: entry j = half interval, LUT sample (j + 1) >> 1).  Proved here for EVERY code
+// the container can hold (0..dtype_max, i.e. also codes above max_code, which the reference clamps to the top of the LUT,
+// clair_torch/models/base.py:146,166) against the reference's float32 arithmetic fl(fl(u / max_code) * (L-1)): floor for
+// LINEAR (base.py:166-168), round-half-even for LOOKUP (base.py:146).  u * scale is evaluated exactly in integers
+// (scale = M 2^-shift), as the FMA does before its one rounding.  A few neighbouring floats are tried for the scale; the
+// verdict is cached per argument set.  CT_ERR_UNSUPPORTED = no such scale (the generic kernel runs instead).
+extern "C" int ct_pivot_interval_constants(float max_code, int n_points, int lookup, int dtype_max, float *scale)
+{
+    struct Entry { float max_code; int n_points, lookup, dtype_max, rc; float scale; };
+    static std::mutex mu;
+    static Entry cache[8];
+    static int used = 0, next = 0;
+    if (!(max_code >= 1.0f) || max_code > 65535.0f || floorf(max_code) != max_code || n_points < 2 || dtype_max < (int)max_code ||
+        dtype_max > 65535)
+        return CT_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int k = 0; k < used; ++k)
+        if (cache[k].max_code == max_code && cache[k].n_points == n_points && cache[k].lookup == lookup && cache[k].dtype_max == dtype_max) {
+            *scale = cache[k].scale;
+            return cache[k].rc;
+        }
+    const int top = n_points - 1, last = lookup ? 2 * top : top;
+    const double want = (double)(lookup ? 2 * top : top) / (double)max_code;
+    float cand[4];
+    cand[0] = (float)want;
+    if ((double)cand[0] < want) cand[0] = nextafterf(cand[0], INFINITY);   // rounded up first: exact multiples stay in their entry
+    cand[1] = nextafterf(cand[0], INFINITY);
+    cand[2] = nextafterf(cand[0], 0.0f);
+    cand[3] = nextafterf(cand[2], 0.0f);
+    int rc = CT_ERR_UNSUPPORTED;
+    float found = 0.0f;
+    for (int c = 0; c < 4 && rc != CT_OK; ++c) {
+        const float r = cand[c];
+        if (!((double)dtype_max * (double)r < 4194304.0)) continue;   // entry + 1.5 * 2^23 must stay exact at ulp 1
+        int e = 0;
+        const double m = frexp((double)r, &e);
+        const uint64_t M = (uint64_t)ldexp(m, 24);
+        const int shift = 24 - e;
+        if (shift < 0 || shift >= 63) continue;
+        bool ok = true;
+        for (int u = 0; ok && u <= dtype_max; ++u) {
+            volatile float x = (float)u / max_code;
+            volatile float s_ref = x * (float)top;
+            float sc = s_ref < 0.0f ? 0.0f : (s_ref > (float)top ? (float)top : s_ref);
+            uint64_t got = ((uint64_t)u * M) >> shift;
+            if (got > (uint64_t)last) got = (uint64_t)last;
+            if (lookup) {
+                float rr = nearbyintf(s_ref);
+                rr = rr < 0.0f ? 0.0f : (rr > (float)top ? (float)top : rr);
+                ok = ((got + 1) >> 1) == (uint64_t)rr;
+            } else {
+                ok = got == (uint64_t)floorf(sc);
+            }
+        }
+        if (ok) {
+            rc = CT_OK;
+            found = r;
+        }
+    }
+    Entry &slot = cache[used < 8 ? used++ : (next++ % 8)];
+    slot = Entry{max_code, n_points, lookup, dtype_max, rc, found};
+    *scale = found;
+    return rc;
+}

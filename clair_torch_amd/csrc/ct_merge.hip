@@ -33,7 +33,13 @@ namespace ct {
 // with K = -2 scale, f'_u = df/ds (per unit of LUT coordinate), s' = sigma / sig_scale (the code u, the pixel x,
 // 1, or the explicit std), so the loop body has no multiply by scale, top, 1/max_code or std_value.
 // FOLD (integer codes only): the pixel value x is never formed; s and dk come straight from the code.
-template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FOLD, int PF = 2>
+// PIVOT (the default since round 3): the second moments are float32 sums about a per-pixel pivot p ~ m_b, exactly as in
+// merge_pivot_kernel below (c_n = b_n - p a_n; Saa, Sac, Scc; conditioning check and one repeat about the known mean) --
+// the float64 moments Saa, Sab, Sbb of round 1 remain behind CT_MERGE_F64_MOMENTS as the independent comparand of the
+// tests.  Besides being cheaper, the pivoted form is the more accurate one where it matters: b_n = a_n y_n is rounded to
+// float32 before the float64 sums ever see it, and for LOOKUP (b = a y exactly) the whole variance is the cancelling
+// part; y_n - p by one FMA does not lose those bits (LOOKUP against the recorded vectors: 1.25e-5 -> ~5e-6).
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FOLD, int PF = 2, bool PIVOT = true>
 __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
 {
     extern __shared__ __align__(16) char lds[];
@@ -43,6 +49,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
     constexpr int kEntry = lut_entry_bytes(INTERP);
     static_assert(!FOLD || kInt, "FOLD is for integer codes");
+    using Moment = std::conditional_t<PIVOT, float, double>;
     const int C = a.channels, L = a.n_points, B = a.batch;
     const int lut_bytes = INTERP == CT_INTERP_NONE ? 0 : C * L * kEntry;
     float *inv_t = reinterpret_cast<float *>(lds + lut_bytes);  // 1 / t_n
@@ -96,23 +103,98 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
         }
     }
 
+    const T *src = static_cast<const T *>(a.stack) + q0;
+    const float *ssrc = STD == CT_STD_EXPLICIT ? a.std_stack + q0 : nullptr;
+    const float dk_mul = FOLD ? kk * a.inv_max_code : kk, dk_add = -0.5f * kk;
+    const bool first = a.flags & CT_MERGE_FIRST_BATCH;
+    const bool finalize = a.flags & CT_MERGE_FINALIZE;
+    const bool keep_state = a.mean_state != nullptr;
+
+    // one sample: pixel (or raw code when FOLD), f(x), df/ds per unit of LUT coordinate
+    auto sample = [&](T code, int roff, float &px, float &lin, float &dfds) {
+        float s;
+        if constexpr (FOLD) {
+            px = (float)code;
+            s = __builtin_fmaf(px, a.index.hi, px * a.index.lo);
+        } else {
+            px = to_pixel<T>(code, a.norm);
+            s = px * top;
+        }
+        if constexpr (INTERP == CT_INTERP_NONE) {
+            lin = FOLD ? px * a.inv_max_code : px;
+            dfds = 1.0f;
+        } else if constexpr (INTERP == CT_INTERP_LOOKUP) {
+            float r = rintf(s);
+            r = kRanged ? fminf(r, top) : fminf(fmaxf(r, 0.0f), top);  // codes are >= 0: only the upper clamp can act
+            lin = reinterpret_cast<const float *>(lds + roff)[(int)r];
+            dfds = 0.0f;
+        } else {
+            float pass = 1.0f;
+            if constexpr (!kRanged) {
+                pass = (s >= 0.0f && s <= top) ? 1.0f : 0.0f;
+                s = fminf(fmaxf(s, 0.0f), top);
+            } else {
+                // a code above max_code: clamp to the top of the LUT like the reference (base.py:166,190); LINEAR's
+                // last staged interval has zero slope, CATMULL needs the explicit gradient mask
+                if constexpr (INTERP == CT_INTERP_CATMULL) pass = s <= top ? 1.0f : 0.0f;
+                s = fminf(s, top);
+            }
+            const int i0 = (int)s;  // s >= 0: truncation is floor
+            const float fr = __builtin_amdgcn_fractf(s);
+            if constexpr (INTERP == CT_INTERP_LINEAR) {
+                const float2 g = reinterpret_cast<const float2 *>(lds + roff)[i0];  // {g[i], g[i+1] - g[i]}
+                dfds = g.y;
+                lin = __builtin_fmaf(dfds, fr, g.x);
+                if constexpr (!kRanged) dfds *= pass;
+            } else {
+                const float4 g = reinterpret_cast<const float4 *>(lds + roff)[i0];
+                const float t = fr, t2 = t * t, t3 = t2 * t;
+                const float w0 = -0.5f * t3 + t2 - 0.5f * t, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
+                const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * t, w3 = 0.5f * t3 - 0.5f * t2;
+                lin = ((w0 * g.x + w1 * g.y) + w2 * g.z) + w3 * g.w;
+                const float d0 = __builtin_fmaf(__builtin_fmaf(-1.5f, t, 2.0f), t, -0.5f);
+                const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
+                const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
+                dfds = __builtin_fmaf(d0, g.x - g.y, __builtin_fmaf(d2, g.z - g.y, d3 * (g.w - g.y)));
+                dfds *= pass;
+            }
+        }
+    };
+
+    // ---- pivot (PIVOT): the running mean of the earlier batches, else the middle exposure's sample ----
+    [[maybe_unused]] float p[V];
+    if constexpr (PIVOT) {
+        if (first) {
+            const int probe = B / 2;
+            const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)probe * a.image_stride);
+            const float itp = inv_t[probe];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float px, lin, dfds;
+                sample(pk.v[e], row_off[e], px, lin, dfds);
+                p[e] = lin * itp;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) p[e] = (float)a.mean_state[a.tile.planar_index(q0 + e)];
+        }
+    }
+
+    double mean_o[V];
+    float std_o[V];
+    for (int pass_no = 0;; ++pass_no) {
     float W[V], Swy[V];
-    double Saa[V], Sab[V], Sbb[V];
+    Moment Saa[V], Sab[V], Sbb[V];  // PIVOT: Saa, Sac, Scc about the pivot (float32); else the raw float64 moments
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         W[e] = 0.0f;
         Swy[e] = 0.0f;
-        Saa[e] = 0.0;
-        Sab[e] = 0.0;
-        Sbb[e] = 0.0;
+        Saa[e] = 0;
+        Sab[e] = 0;
+        Sbb[e] = 0;
     }
 
-    const T *src = static_cast<const T *>(a.stack) + q0;
-    const float *ssrc = STD == CT_STD_EXPLICIT ? a.std_stack + q0 : nullptr;
-    const float dk_mul = FOLD ? kk * a.inv_max_code : kk, dk_add = -0.5f * kk;
-
-    // Software pipeline: PF packets (16-byte loads) are in flight per thread ahead of the one being reduced, and
-    // the V LDS gathers of a packet are issued together before any of them is consumed.
+    // Software pipeline: PF packets (16-byte loads) are in flight per thread ahead of the one being reduced.
     Packet<T, V> ring[PF];  // ring[0] is the packet being reduced; rotation is by register renaming after unroll
     Packet<float, V> sring[STD == CT_STD_EXPLICIT ? PF : 1];
 #pragma unroll
@@ -145,79 +227,13 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
         if constexpr (STD == CT_STD_EXPLICIT) sring[PF - 1] = sincoming;
         const float it = inv_t[n];
         const float cqn = cq[n];
-        // ---- stage A: pixel / LUT coordinate, issue the LDS gathers ----
-        float pxv[V], frv[V], passv[V];
-        float ga[V], gb[V], gc[V], gd[V];  // LUT taps (LINEAR: a,b; CATMULL: a..d; LOOKUP: a)
+        float pxv[V], linv[V], dfv[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) sample(pk.v[e], row_off[e], pxv[e], linv[e], dfv[e]);  // the V LDS gathers issue together
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            float px, s;
-            if constexpr (FOLD) {
-                px = (float)pk.v[e];
-                s = __builtin_fmaf(px, a.index.hi, px * a.index.lo);
-            } else {
-                px = to_pixel<T>(pk.v[e], a.norm);
-                s = px * top;
-            }
-            pxv[e] = px;
-            passv[e] = 1.0f;
-            frv[e] = 0.0f;
-            ga[e] = gb[e] = gc[e] = gd[e] = 0.0f;
-            if constexpr (INTERP == CT_INTERP_LOOKUP) {
-                float r = rintf(s);
-                r = kRanged ? fminf(r, top) : fminf(fmaxf(r, 0.0f), top);  // codes are >= 0: only the upper clamp can act
-                ga[e] = reinterpret_cast<const float *>(lds + row_off[e])[(int)r];
-            } else if constexpr (INTERP != CT_INTERP_NONE) {
-                if constexpr (!kRanged) {
-                    passv[e] = (s >= 0.0f && s <= top) ? 1.0f : 0.0f;
-                    s = fminf(fmaxf(s, 0.0f), top);
-                } else {
-                    // a code above max_code: clamp to the top of the LUT like the reference (base.py:166,190); LINEAR's
-                    // last staged interval has zero slope, CATMULL needs the explicit gradient mask
-                    if constexpr (INTERP == CT_INTERP_CATMULL) passv[e] = s <= top ? 1.0f : 0.0f;
-                    s = fminf(s, top);
-                }
-                const int i0 = (int)s;  // s >= 0: truncation is floor
-                frv[e] = __builtin_amdgcn_fractf(s);
-                if constexpr (INTERP == CT_INTERP_LINEAR) {
-                    const float2 g = reinterpret_cast<const float2 *>(lds + row_off[e])[i0];
-                    ga[e] = g.x;
-                    gb[e] = g.y;
-                } else {
-                    const float4 g = reinterpret_cast<const float4 *>(lds + row_off[e])[i0];
-                    ga[e] = g.x;
-                    gb[e] = g.y;
-                    gc[e] = g.z;
-                    gd[e] = g.w;
-                }
-            }
-        }
-        // ---- stage B: f(x), weight, running sums ----
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float px = pxv[e];
-            float lin, dfds;
-            if constexpr (INTERP == CT_INTERP_NONE) {
-                lin = FOLD ? px * a.inv_max_code : px;
-                dfds = 1.0f;
-            } else if constexpr (INTERP == CT_INTERP_LOOKUP) {
-                lin = ga[e];
-                dfds = 0.0f;
-            } else if constexpr (INTERP == CT_INTERP_LINEAR) {
-                dfds = gb[e];  // the staged table holds {g[i], g[i+1] - g[i]}
-                lin = __builtin_fmaf(dfds, frv[e], ga[e]);
-                if constexpr (!kRanged) dfds *= passv[e];
-            } else {
-                const float t = frv[e], t2 = t * t, t3 = t2 * t;
-                const float w0 = -0.5f * t3 + t2 - 0.5f * t, w1 = 1.5f * t3 - 2.5f * t2 + 1.0f;
-                const float w2 = -1.5f * t3 + 2.0f * t2 + 0.5f * t, w3 = 0.5f * t3 - 0.5f * t2;
-                lin = ((w0 * ga[e] + w1 * gb[e]) + w2 * gc[e]) + w3 * gd[e];
-                const float d0 = __builtin_fmaf(__builtin_fmaf(-1.5f, t, 2.0f), t, -0.5f);
-                const float d2 = __builtin_fmaf(__builtin_fmaf(-4.5f, t, 4.0f), t, 0.5f);
-                const float d3 = __builtin_fmaf(1.5f, t, -1.0f) * t;
-                dfds = __builtin_fmaf(d0, ga[e] - gb[e], __builtin_fmaf(d2, gc[e] - gb[e], d3 * (gd[e] - gb[e])));
-                dfds *= passv[e];
-            }
-            const float y = lin * it;
+            const float px = pxv[e], lin = linv[e], dfds = dfv[e];
+            const float y = PIVOT ? __builtin_fmaf(lin, it, -p[e]) : lin * it;  // PIVOT: y_n - p
             float sg = 1.0f;
             if constexpr (STD == CT_STD_EXPLICIT) sg = sp.v[e];
             if constexpr (STD == CT_STD_MULTIPLIER) sg = px;
@@ -229,70 +245,121 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
                 if constexpr (kHasStd) {
                     const float wu = (STD == CT_STD_CONSTANT) ? w : w * sg;
                     const float av = dk * wu;
-                    float bv;
+                    float bv;  // PIVOT: c_n = b_n - p a_n
                     if constexpr (INTERP == CT_INTERP_LOOKUP)
                         bv = av * y;
                     else if constexpr (INTERP == CT_INTERP_NONE)
                         bv = __builtin_fmaf(av, y, wu * cqn);
                     else
                         bv = __builtin_fmaf(av, y, (wu * dfds) * cqn);
-                    // float64 FMAs: the quadratic form below cancels by 1e2..1e4 (LOOKUP: b = a y exactly);
-                    // float32 block sums were measured 7 % faster and 1.3e-4 off on such cases -- not worth it.
-                    const double ad = (double)av, bd = (double)bv;
-                    Saa[e] = __builtin_fma(ad, ad, Saa[e]);
-                    Sab[e] = __builtin_fma(ad, bd, Sab[e]);
-                    Sbb[e] = __builtin_fma(bd, bd, Sbb[e]);
+                    if constexpr (PIVOT) {
+                        Saa[e] = __builtin_fmaf(av, av, Saa[e]);
+                        Sab[e] = __builtin_fmaf(av, bv, Sab[e]);
+                        Sbb[e] = __builtin_fmaf(bv, bv, Sbb[e]);
+                    } else {
+                        // float64 FMAs: the quadratic form below cancels by 1e2..1e4 (LOOKUP: b = a y exactly)
+                        const double ad = (double)av, bd = (double)bv;
+                        Saa[e] = __builtin_fma(ad, ad, Saa[e]);
+                        Sab[e] = __builtin_fma(ad, bd, Sab[e]);
+                        Sbb[e] = __builtin_fma(bd, bd, Sbb[e]);
+                    }
                 }
             } else {
                 Swy[e] += y;
                 if constexpr (kHasStd) {
                     const float bv = (INTERP == CT_INTERP_NONE ? sg : dfds * sg) * cqn;
-                    const double bd = (double)bv;
-                    Sbb[e] = __builtin_fma(bd, bd, Sbb[e]);
+                    if constexpr (PIVOT) {
+                        Sbb[e] = __builtin_fmaf(bv, bv, Sbb[e]);
+                    } else {
+                        const double bd = (double)bv;
+                        Sbb[e] = __builtin_fma(bd, bd, Sbb[e]);
+                    }
                 }
             }
         }
     }
 
-    const bool first = a.flags & CT_MERGE_FIRST_BATCH;
-    const bool finalize = a.flags & CT_MERGE_FINALIZE;
-    const bool keep_state = a.mean_state != nullptr;
     // scale of the folded second moments back to true units
     double fs = 1.0;
     if constexpr (kGauss) fs = (double)K / (double)kk;
     if constexpr (STD == CT_STD_CONSTANT) fs *= (double)a.std_value;
     if constexpr (STD == CT_STD_MULTIPLIER) fs *= (double)a.std_value * (FOLD ? (double)a.inv_max_code : 1.0);
     const double sv2 = fs * fs;
-    double mean_o[V];
-    float std_o[V];
+    bool any_bad = false;
+    [[maybe_unused]] float mb_f[V];
+    [[maybe_unused]] bool bad[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         const uint32_t q = a.tile.planar_index(q0 + e);  // state and outputs are planar (C, H, W)
         float Wb = W[e];
         if constexpr (!kGauss) Wb = (float)B;
         const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
-        const double D = (double)Df;
-        const double mb = (double)Swy[e] / D;
         const float WA = first ? 0.0f : a.sumw_state[q];
         const double meanA = first ? 0.0 : a.mean_state[q];
         const float Wt = WA + Wb;
         const float frac = Wb / Wt;  // float32 division (statistics.py:105)
-        const double mean = meanA + (double)frac * (mb - meanA);
+        double mean;
         float var = 0.0f;
-        if constexpr (kHasStd) {
-            const double beta = (double)frac / D;
-            const double alpha = ((double)WA / ((double)Wt * (double)Wt)) * (mb - meanA) - beta * mb;
-            const double upd = (alpha * alpha * Saa[e] + 2.0 * alpha * beta * Sab[e] + beta * beta * Sbb[e]) * sv2;
-            var = (first ? 0.0f : a.var_state[q]) + (float)upd;
-        }
-        if (keep_state) {
-            a.mean_state[q] = mean;
-            a.sumw_state[q] = Wt;
-            if constexpr (kHasStd) a.var_state[q] = var;
+        if constexpr (PIVOT) {
+            // as merge_pivot_kernel's epilogue: m_b - p from the sums about the pivot, variance from the three float32 moments
+            float r = __builtin_amdgcn_rcpf(Df);
+            r = r * __builtin_fmaf(-Df, r, 2.0f);
+            const float num = __builtin_fmaf(-p[e], 1e-6f, Swy[e]);  // sum w y - p (W + 1e-6)
+            float qd = num * r;
+            qd = __builtin_fmaf(__builtin_fmaf(-qd, Df, num), r, qd);  // m_b - p
+            const double diff = ((double)p[e] - meanA) + (double)qd;   // m_b - mean_A
+            mean = __builtin_fma((double)frac, diff, meanA);
+            mb_f[e] = p[e] + qd;
+            bad[e] = false;
+            if constexpr (kHasStd) {
+                const float gam = first ? 0.0f : (WA / (Wt * Wt)) * (float)diff;
+                const float beta = frac * r;
+                const float kap = __builtin_fmaf(-beta, qd, gam);
+                const float t1 = beta * beta * Sbb[e];
+                const float t2 = 2.0f * beta * kap * Sab[e];
+                const float t3 = kap * kap * Saa[e];
+                const float upd = (t1 + t2) + t3;
+                if constexpr (kGauss) bad[e] = (t1 + fabsf(t2)) + t3 > kPivotCondLimit * upd;
+                var = (first ? 0.0f : a.var_state[q]) + fmaxf(upd, 0.0f) * (float)sv2;
+            }
+            any_bad |= bad[e];
+        } else {
+            const double D = (double)Df;
+            const double mb = (double)Swy[e] / D;
+            mean = meanA + (double)frac * (mb - meanA);
+            if constexpr (kHasStd) {
+                const double beta = (double)frac / D;
+                const double alpha = ((double)WA / ((double)Wt * (double)Wt)) * (mb - meanA) - beta * mb;
+                const double upd = (alpha * alpha * (double)Saa[e] + 2.0 * alpha * beta * (double)Sab[e] + beta * beta * (double)Sbb[e]) * sv2;
+                var = (first ? 0.0f : a.var_state[q]) + (float)upd;
+            }
         }
         mean_o[e] = mean;
-        std_o[e] = __builtin_amdgcn_sqrtf(var);
+        std_o[e] = var;  // the variance until the stores below
+        W[e] = Wt;       // (re-used as the output total weight)
     }
+    if constexpr (PIVOT) {
+        // an ill-conditioned pivot anywhere in the wavefront: repeat the batch once with those elements' pivot at the now
+        // known mean; the others recompute bit-identically, so an element's result does not depend on its neighbours
+        if (pass_no == 0 && __any(any_bad)) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) p[e] = bad[e] ? mb_f[e] : p[e];
+            continue;
+        }
+    }
+    if (keep_state) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const uint32_t q = a.tile.planar_index(q0 + e);
+            a.mean_state[q] = mean_o[e];
+            a.sumw_state[q] = W[e];
+            if constexpr (kHasStd) a.var_state[q] = std_o[e];
+        }
+    }
+    break;
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) std_o[e] = __builtin_amdgcn_sqrtf(std_o[e]);
     if (finalize && a.tile.layout != CT_LAYOUT_NCHW) {
         // interleaved input: the V elements of this thread belong to different planes -> element-wise stores
 #pragma unroll
@@ -453,11 +520,16 @@ __device__ __forceinline__ void static_for(F &&f)
 }
 
 struct PivotArgs {
-    uint32_t index_mul;  // floor(code * (L-1) / max_code) == (code * index_mul) >> 32 for every code (uint16 only)
-    float step;          // max_code / (L-1), an integer
+    uint32_t index_mul;  // floor(code * (L-1) / max_code) == (code * index_mul) >> 32 for every code (raw-load build, uint16 only)
+    float step;          // max_code / (L-1): codes per LUT interval (any positive value; a whole number on the headline shapes)
     uint32_t n_tiles;    // tiles of kBlock * V elements
     int32_t probe;       // exposure whose sample seeds the pivot of a first batch
-    float index_rcp;     // 1 / step rounded up: floor(code / step) by one round-down FMA (typed-load path)
+    float index_rcp;     // table entry of a code = floor(code * index_rcp) by one round-down FMA (typed-load path): (L-1) / max_code
+                         // for LINEAR, 2 (L-1) / max_code for LOOKUP (half intervals), rounded so that EVERY code the container
+                         // can hold lands in the reference's entry (ct_pivot_interval_constants)
+    float max_code;      // what Normalize divides by
+    float tf_max;        // CLAMP: 1.5 * 2^23 + last table entry (codes above max_code clamp to the top of the LUT, base.py:166)
+    uint32_t n_entries;  // table entries per LUT row: L (LINEAR), 2 L (LOOKUP)
     unsigned long long *retry_count;  // diagnostics: wavefronts that ran the fallback pass (may be NULL)
 };
 
@@ -465,7 +537,6 @@ struct PivotArgs {
 #define CT_PIVOT_DEPTH 2
 #endif
 constexpr int kPivotDepth = CT_PIVOT_DEPTH;  // exposures in flight per thread
-constexpr float kPivotCondLimit = 8.0f;
 constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which the table keeps {g[i], S}: error bound 2^-25 * 64 = 2e-6  // sum |terms| / result above which a wavefront repeats the batch about the mean
 
 // Experiments with the weight evaluation (measured in profiles/r03_merge_weight_variants.md):
@@ -488,13 +559,15 @@ constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which
 #ifndef CT_PIVOT_KERNEL_ATTR
 #define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? 7 : 8) : 4, 8)))
 #endif
-template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST>
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST, bool CLAMP = false>
 __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kernel(const MergeArgs a, const PivotArgs x)
 {
     extern __shared__ __align__(16) char lds[];
     static_assert(sizeof(T) != 4, "raw integer codes only");
-    static_assert(INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_NONE, "LOOKUP / CATMULL use merge_kernel");
-    constexpr bool kLut = INTERP == CT_INTERP_LINEAR;
+    static_assert(INTERP != CT_INTERP_CATMULL, "CATMULL uses merge_kernel / merge_reference_order_kernel");
+    static_assert(CT_PIVOT_TYPED_LOAD || (INTERP != CT_INTERP_LOOKUP && !CLAMP), "raw-load build: whole-step LINEAR only");
+    constexpr bool kLut = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;  // a table in LDS
+    constexpr bool kLookup = INTERP == CT_INTERP_LOOKUP;  // piecewise constant: entry j = half interval j, slope 0, row = channel
     constexpr bool kHasStd = STD != CT_STD_NONE;
     constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
     constexpr bool kTyped = CT_PIVOT_TYPED_LOAD;  // codes arrive as floats from typed buffer loads
@@ -502,33 +575,44 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     const int C = a.channels, L = a.n_points, B = a.batch;
     constexpr int kWV = (kLut && kGauss && kTyped && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;  // weight evaluation variant
     constexpr int kEntryShift = kWV == 2 ? 4 : 3;
-    const int lut_bytes = kLut ? C * L * (1 << kEntryShift) : 0;
+    const int E = kLut ? (int)x.n_entries : 0;  // table entries per row
+    const int lut_bytes = C * E * (1 << kEntryShift);
     float2 *expo = reinterpret_cast<float2 *>(lds + lut_bytes);  // per exposure {1 / t_n, chain factor of the y' term}
     [[maybe_unused]] const uint32_t wt_base = (uint32_t)lut_bytes + 8u * (uint32_t)B;  // kWV == 1: the weight table
     const float kk = sqrtf(a.weight_scale * 1.4426950408889634f);
     const float dk_mul = kk * a.inv_max_code, dk_add = -0.5f * kk;
     const float K = -2.0f * a.weight_scale;
     // y' = (df/dcode) max_code / t_n;  the loop forms (w s' df/dcode) * cq_n with cq_n = max_code (kk / K) / t_n
-    const float max_code = kLut ? x.step * (float)(L - 1) : 1.0f;  // (no model: df/dcode * max_code = 1, folded)
+    const float max_code = kLut ? x.max_code : 1.0f;  // (no model: df/dcode * max_code = 1, folded)
     const float ce = kGauss ? max_code * kk / K : max_code;
 
     bool rough = false;
-    if constexpr (kLut) {
+    if constexpr (kLookup) {
+        // entry j of row c covers LUT coordinates [j / 2, (j + 1) / 2): the reference's round-half-even index is (j + 1) / 2
+        // for every code (host-verified), so f = g[c][(j + 1) >> 1] and the slope is zero
+        const int total = C * E;
+        for (int k = threadIdx.x; k < total; k += kBlock) {
+            const int r = k / E, j = k - r * E;
+            const int idx = (j + 1) >> 1;
+            reinterpret_cast<float2 *>(lds)[k] = make_float2(a.lut[(size_t)r * L + (idx < L ? idx : L - 1)], 0.0f);
+        }
+    } else if constexpr (kLut) {
         // entry i of row r: f(code) = A + S * code on [i * step, (i + 1) * step):  S = (g[i+1] - g[i]) / step (the
         // reference backward's g1 - g0), A = g[i] - S * i * step formed in float64 and rounded once.  One FMA per
         // sample, but A carries an absolute rounding error of 2^-25 |A|, and |A| <= |g[i]| + i |g[i+1] - g[i]| exceeds
         // the LUT values themselves when the curve is steep: a factor 1 + p for g = x^p, unbounded for a LUT with a
         // jump.  A workgroup that meets |A| > kRoughLimit max(|g[i]|, |g[i+1]|) anywhere therefore stages {g[i], S}
-        // instead and evaluates f = g[i] + S (code - i * step) with the offset formed exactly (two more instructions
-        // per sample); every workgroup sees the same LUT, so all take the same branch.
+        // instead and evaluates f = g[i] + S (code - i * step) with the offset formed exactly when the step is a whole
+        // number of codes (two more instructions per sample); every workgroup sees the same LUT, so all take the same branch.
         const int total = C * L;
+        const double stepd = (double)x.max_code / (double)(L - 1);
         bool viol = false;
         for (int k = threadIdx.x; k < total; k += kBlock) {
             const int r = k / L, i = k - r * L;
             const float *row = a.lut + (size_t)r * L;
             const float g0 = row[i], g1 = row[i + 1 < L ? i + 1 : L - 1];
             const float slope = (g1 - g0) / x.step;
-            const float A = (float)((double)g0 - (double)slope * ((double)i * (double)x.step));
+            const float A = (float)((double)g0 - (double)slope * ((double)i * stepd));
             viol |= !(fabsf(A) <= kRoughLimit * fmaxf(fmaxf(fabsf(g0), fabsf(g1)), 1e-30f));
         }
         rough = __syncthreads_or(viol);
@@ -537,7 +621,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             const float *row = a.lut + (size_t)r * L;
             const float g0 = row[i], g1 = row[i + 1 < L ? i + 1 : L - 1];
             const float slope = (g1 - g0) / x.step;
-            const float A = (float)((double)g0 - (double)slope * ((double)i * (double)x.step));
+            const float A = (float)((double)g0 - (double)slope * ((double)i * stepd));
             if constexpr (kWV == 2) {
                 const double dki = (double)i * (double)x.step * (double)dk_mul + (double)dk_add;
                 reinterpret_cast<float4 *>(lds)[k] =
@@ -594,10 +678,11 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    row_off[e] = r * L * 8;
+                    row_off[e] = (kLookup ? ch : r) * E * 8;  // LOOKUP: the true channel (base.py:149-155)
                     int inc = 1;
                     if (++off == a.tile.plane_local) {
                         off = 0;
+                        ++ch;
                         inc += skip_mod;
                     }
                     r += inc;
@@ -609,7 +694,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     int ch;
                     uint32_t qg;
                     a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
-                    row_off[e] = (int)(qg % (uint32_t)C) * L * 8;
+                    row_off[e] = (kLookup ? ch : (int)(qg % (uint32_t)C)) * E * 8;
                 }
             }
         } else {
@@ -635,6 +720,10 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             const float itp = expo[x.probe].x;
             float tf[V];
             if constexpr (kLut) floor_index_bits<V>(pk.v, index_rcp, floor_magic, tf);
+            if constexpr (kLut && CLAMP) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) tf[e] = fminf(tf[e], x.tf_max);
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float px = pk.v[e];
@@ -695,6 +784,10 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                         floor_index_bits2<V>(pxv, index_rcp, 1.0f / (float)(1 << CT_PIVOT_WT_SHIFT), floor_magic, tf, tw);
                     else if constexpr (kLut)
                         floor_index_bits<V>(pxv, index_rcp, floor_magic, tf);
+                    if constexpr (kLut && CLAMP) {  // a code above max_code: the last entry (top of the LUT, zero slope)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) tf[e] = fminf(tf[e], x.tf_max);
+                    }
                 }
                 static_for<V>([&](auto ec) {  // stage A: the V table gathers and the V transcendentals, each issued together
                     constexpr int e = decltype(ec)::value;
@@ -760,7 +853,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 #pragma unroll
                 for (int e = 0; e < V; ++e) {  // stage B: f, weight, running sums
                     const float px = pxv[e];
-                    const float lin = kLut ? __builtin_fmaf(gs[e], kRough ? pxl[e] : px, ga[e]) : px * a.inv_max_code;
+                    const float lin = kLookup ? ga[e] : kLut ? __builtin_fmaf(gs[e], kRough ? pxl[e] : px, ga[e]) : px * a.inv_max_code;
                     const float yd = __builtin_fmaf(lin, it, -p[e]);  // y_n - p
                     if constexpr (kGauss) {
                         const float dk = dkv[e], w = wv[e];
@@ -771,8 +864,13 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                             if constexpr (STD == CT_STD_MULTIPLIER) wu = w * px;
                             if constexpr (STD == CT_STD_EXPLICIT) wu = w * sp.v[e];
                             const float av = dk * wu;
-                            const float ev = kLut ? (wu * gs[e]) * cqn : wu * cqn;
-                            const float cv = __builtin_fmaf(av, yd, ev);
+                            float cv;
+                            if constexpr (kLookup) {
+                                cv = av * yd;  // no gradient through the index: the whole variance is the weight path
+                            } else {
+                                const float ev = kLut ? (wu * gs[e]) * cqn : wu * cqn;
+                                cv = __builtin_fmaf(av, yd, ev);
+                            }
                             Saa[e] = __builtin_fmaf(av, av, Saa[e]);
                             Sac[e] = __builtin_fmaf(av, cv, Sac[e]);
                             Scc[e] = __builtin_fmaf(cv, cv, Scc[e]);
@@ -948,39 +1046,70 @@ static int launch_pivot_grid(const MergeArgs &a, const PivotArgs &x, size_t lds,
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
-template <typename T, int V, int INTERP, int WEIGHT, int STD>
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool CLAMP>
 static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
 {
     if (a.q_count == 0) return CT_OK;
-    x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
-    constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && CT_PIVOT_TYPED_LOAD && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;
-    const size_t lds = (INTERP == CT_INTERP_LINEAR ? (size_t)a.channels * a.n_points * (kWV == 2 ? 16 : 8) : 0) +
-                       2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
-    if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
-    return (a.flags & CT_MERGE_FIRST_BATCH) ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true>>(a, x, lds, stream)
-                                            : launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false>>(a, x, lds, stream);
+    if constexpr (INTERP == CT_INTERP_LOOKUP && WEIGHT == CT_WEIGHT_NONE && STD != CT_STD_NONE) {
+        return CT_ERR_NO_GRADIENT_PATH;  // (refused by ct_hdr_merge_batch before it gets here)
+    } else {
+        x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
+        constexpr bool kTable = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;
+        constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && CT_PIVOT_TYPED_LOAD && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;
+        const size_t lds = (kTable ? (size_t)a.channels * x.n_entries * (kWV == 2 ? 16 : 8) : 0) +
+                           2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
+        if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+        return (a.flags & CT_MERGE_FIRST_BATCH)
+                   ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true, CLAMP>>(a, x, lds, stream)
+                   : launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false, CLAMP>>(a, x, lds, stream);
+    }
 }
 
-template <typename T, int V, int INTERP, int WEIGHT>
+template <typename T, int V, int INTERP, int WEIGHT, bool CLAMP>
 static int dispatch_pivot_std(const MergeArgs &a, const PivotArgs &x, int std_mode, hipStream_t s)
 {
     switch (std_mode) {
-        case CT_STD_NONE: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, x, s);
-        case CT_STD_CONSTANT: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, x, s);
-        case CT_STD_MULTIPLIER: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER>(a, x, s);
-        case CT_STD_EXPLICIT: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT>(a, x, s);
+        case CT_STD_NONE: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_NONE, CLAMP>(a, x, s);
+        case CT_STD_CONSTANT: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, CLAMP>(a, x, s);
+        case CT_STD_MULTIPLIER: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, CLAMP>(a, x, s);
+        case CT_STD_EXPLICIT: return launch_pivot<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, CLAMP>(a, x, s);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
 
-template <typename T, int V>
-static int dispatch_pivot(const MergeArgs &a, const PivotArgs &x, int interp, int weight_mode, int std_mode, hipStream_t s)
+template <typename T, int V, bool CLAMP>
+static int dispatch_pivot_interp(const MergeArgs &a, const PivotArgs &x, int interp, int weight_mode, int std_mode, hipStream_t s)
 {
+    const bool gauss = weight_mode == CT_WEIGHT_GAUSS;
     if (interp == CT_INTERP_LINEAR)
-        return weight_mode == CT_WEIGHT_GAUSS ? dispatch_pivot_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS>(a, x, std_mode, s)
-                                              : dispatch_pivot_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_NONE>(a, x, std_mode, s);
-    return weight_mode == CT_WEIGHT_GAUSS ? dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_GAUSS>(a, x, std_mode, s)
-                                          : dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE>(a, x, std_mode, s);
+        return gauss ? dispatch_pivot_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
+                     : dispatch_pivot_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
+    if constexpr (CT_PIVOT_TYPED_LOAD) {
+        if (interp == CT_INTERP_LOOKUP)
+            return gauss ? dispatch_pivot_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
+                         : dispatch_pivot_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
+    }
+    // no model: no table, nothing to clamp
+    return gauss ? dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_GAUSS, false>(a, x, std_mode, s)
+                 : dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE, false>(a, x, std_mode, s);
+}
+
+// CLAMP (codes above max_code exist: max_code below the container's range) costs one v_min per sample, so it is its own
+// instantiation for uint16 packets; the one-element launch of a ragged tail always carries it (its cost is irrelevant);
+// uint8 packets with max_code < 255 are left to the generic kernel (pivot_eligible).
+template <typename T, int V>
+static int dispatch_pivot(const MergeArgs &a, const PivotArgs &x, int interp, int weight_mode, int std_mode, bool clamp, hipStream_t s)
+{
+    if constexpr (!CT_PIVOT_TYPED_LOAD) {
+        return dispatch_pivot_interp<T, V, false>(a, x, interp, weight_mode, std_mode, s);
+    } else if constexpr (V == 1) {
+        return dispatch_pivot_interp<T, V, true>(a, x, interp, weight_mode, std_mode, s);
+    } else if constexpr (sizeof(T) == 2) {
+        return clamp ? dispatch_pivot_interp<T, V, true>(a, x, interp, weight_mode, std_mode, s)
+                     : dispatch_pivot_interp<T, V, false>(a, x, interp, weight_mode, std_mode, s);
+    } else {
+        return dispatch_pivot_interp<T, V, false>(a, x, interp, weight_mode, std_mode, s);
+    }
 }
 
 template <typename T, int V, int INTERP, int WEIGHT, int STD>
@@ -992,13 +1121,20 @@ static int launch_one(const MergeArgs &a, hipStream_t stream, bool fold)
     const size_t lds = (INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP)) +
                        2 * sizeof(float) * (size_t)a.batch;
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+    const bool f64 = a.flags & CT_MERGE_F64_MOMENTS;  // diagnostic: the round-1 float64 moments
     if constexpr (sizeof(T) != 4) {
-        if (fold)
-            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, true>), dim3(grid), dim3(kBlock), lds, stream, a);
+        if (fold && f64)
+            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, true, 2, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+        else if (fold)
+            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, true, 2, true>), dim3(grid), dim3(kBlock), lds, stream, a);
+        else if (f64)
+            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false, 2, false>), dim3(grid), dim3(kBlock), lds, stream, a);
         else
-            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+            hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false, 2, true>), dim3(grid), dim3(kBlock), lds, stream, a);
+    } else if (f64) {
+        hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false, 2, false>), dim3(grid), dim3(kBlock), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false>), dim3(grid), dim3(kBlock), lds, stream, a);
+        hipLaunchKernelGGL((merge_kernel<T, V, INTERP, WEIGHT, STD, false, 2, true>), dim3(grid), dim3(kBlock), lds, stream, a);
     }
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
@@ -1051,7 +1187,7 @@ struct VecWidth {
 
 template <typename T>
 static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s, bool fold,
-                       const PivotArgs *pivot = nullptr)
+                       const PivotArgs *pivot = nullptr, bool pivot_clamp = false)
 {
     constexpr int V = VecWidth<T>::value;
     // The packet path needs every packet naturally aligned in every exposure: base pointers and the image
@@ -1075,13 +1211,13 @@ static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int
             if (q_pv) {
                 a.q_begin = 0;
                 a.q_count = q_pv;
-                rc = dispatch_pivot<T, kPivotV>(a, *pivot, interp, weight_mode, std_mode, s);
+                rc = dispatch_pivot<T, kPivotV>(a, *pivot, interp, weight_mode, std_mode, pivot_clamp, s);
                 if (rc != CT_OK) return rc;
             }
             if (q_pv < Q) {
                 a.q_begin = q_pv;
                 a.q_count = Q - q_pv;
-                rc = dispatch_pivot<T, 1>(a, *pivot, interp, weight_mode, std_mode, s);
+                rc = dispatch_pivot<T, 1>(a, *pivot, interp, weight_mode, std_mode, pivot_clamp, s);
             }
             return rc;
         }
@@ -1115,27 +1251,44 @@ extern "C" int ct_pivot_floor_constants(float max_code, int n_points, float *rcp
 static unsigned long long *g_merge_retry_counter = nullptr;
 extern "C" void ct_merge_set_retry_counter(unsigned long long *counter_dev) { g_merge_retry_counter = counter_dev; }
 
-// Pivoted float32 kernel: LINEAR / no model on full-range codes whose LUT interval is an exact integer function of the
-// code (step = max_code / (L-1) integral, verified for every code on the host); CT_MERGE_F64_MOMENTS opts out.
-static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_points, uint32_t flags, ct::PivotArgs *px)
+// Host proof behind the pivoted kernel's table addressing (ct_api.cpp).
+extern "C" int ct_pivot_interval_constants(float max_code, int n_points, int lookup, int dtype_max, float *scale);
+
+// Pivoted float32 kernel: LINEAR / LOOKUP / no model on raw integer codes whose table entry is an exact function of the
+// code by one round-down FMA -- verified on the host for every code the container can hold, also above max_code (12- and
+// 14-bit data in uint16) and for LUT steps that are not a whole number of codes; CT_MERGE_F64_MOMENTS opts out.
+// *clamp: codes above max_code exist and must clamp to the last entry.
+static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_points, uint32_t flags, ct::PivotArgs *px,
+                           bool *clamp = nullptr)
 {
     if (dtype != CT_DTYPE_U8 && dtype != CT_DTYPE_U16) return false;
-    const float dtype_max = dtype == CT_DTYPE_U8 ? 255.0f : 65535.0f;
-    if ((flags & CT_MERGE_F64_MOMENTS) || max_code != dtype_max) return false;
-    if (interp != CT_INTERP_LINEAR && interp != CT_INTERP_NONE) return false;
+    const int dtype_max = dtype == CT_DTYPE_U8 ? 255 : 65535;
+    if (flags & CT_MERGE_F64_MOMENTS) return false;
+    if (!(max_code >= 1.0f) || max_code > (float)dtype_max || floorf(max_code) != max_code) return false;
+    if (interp != CT_INTERP_LINEAR && interp != CT_INTERP_NONE && interp != CT_INTERP_LOOKUP) return false;
+    const bool need_clamp = interp != CT_INTERP_NONE && max_code < (float)dtype_max;
+    if (clamp) *clamp = need_clamp;
     px->step = 1.0f;
     px->index_mul = 0;
     px->index_rcp = 1.0f;
-    if (interp == CT_INTERP_LINEAR) {
-        if (CT_PIVOT_TYPED_LOAD) {  // any whole step: the interval comes from the round-down FMA on the float code
-            if (ct_pivot_floor_constants(max_code, n_points, &px->index_rcp) != CT_OK) return false;
-            px->step = (float)((int)max_code / (n_points - 1));
-        } else {
-            if (ct_pivot_index_constants(max_code, n_points, &px->index_mul, &px->step) != CT_OK) return false;
-            if (dtype == CT_DTYPE_U8 && px->step != 1.0f) return false;   // raw uint8 codes: the code is the index
-            if (dtype == CT_DTYPE_U16 && px->index_mul == 0) return false;
-        }
+    px->max_code = max_code;
+    px->n_entries = 0;
+    px->tf_max = ct::kFloorMagic;
+    if (interp == CT_INTERP_NONE) return true;
+    if (CT_PIVOT_TYPED_LOAD) {
+        if (need_clamp && dtype == CT_DTYPE_U8) return false;  // (no CLAMP instantiation for uint8 packets)
+        const bool lookup = interp == CT_INTERP_LOOKUP;
+        if (ct_pivot_interval_constants(max_code, n_points, lookup, dtype_max, &px->index_rcp) != CT_OK) return false;
+        px->step = (float)((double)max_code / (double)(n_points - 1));
+        px->n_entries = lookup ? 2u * (uint32_t)n_points : (uint32_t)n_points;
+        px->tf_max = ct::kFloorMagic + (float)(lookup ? 2 * (n_points - 1) : n_points - 1);
+        return true;
     }
+    if (interp != CT_INTERP_LINEAR || need_clamp) return false;
+    if (ct_pivot_index_constants(max_code, n_points, &px->index_mul, &px->step) != CT_OK) return false;
+    if (dtype == CT_DTYPE_U8 && px->step != 1.0f) return false;   // raw uint8 codes: the code is the index
+    if (dtype == CT_DTYPE_U16 && px->index_mul == 0) return false;
+    px->n_entries = (uint32_t)n_points;
     return true;
 }
 
@@ -1162,8 +1315,11 @@ extern "C" const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, i
                      "thread through typed buffer loads, 7 wavefronts per SIMD, first batch)"
                    : "ct::merge_pivot_kernel (float32 moments about the running mean, persistent workgroups, 4 codes per "
                      "thread, streaming state)";
-    return dtype == CT_DTYPE_F32 ? "ct::merge_kernel (float64 moments, float32 pixels, 4 per thread)"
-                                 : "ct::merge_kernel (float64 moments, integer codes)";
+    if (flags & CT_MERGE_F64_MOMENTS)
+        return dtype == CT_DTYPE_F32 ? "ct::merge_kernel (float64 moments, float32 pixels, 4 per thread)"
+                                     : "ct::merge_kernel (float64 moments, integer codes)";
+    return dtype == CT_DTYPE_F32 ? "ct::merge_kernel (float32 moments about a per-pixel pivot, float32 pixels, 4 per thread)"
+                                 : "ct::merge_kernel (float32 moments about a per-pixel pivot, integer codes through the float LUT coordinate)";
 }
 
 extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int32_t batch,
@@ -1234,13 +1390,14 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
             a.inv_max_code = (float)(1.0 / (double)max_code);
             PivotArgs px{};
             const PivotArgs *pivot = nullptr;
-            if (pivot_eligible(dtype, max_code, interp, a.n_points, flags, &px)) {
+            bool clamp = false;
+            if (pivot_eligible(dtype, max_code, interp, a.n_points, flags, &px, &clamp)) {
                 px.probe = batch / 2;
                 px.retry_count = g_merge_retry_counter;
                 pivot = &px;
             }
-            return dtype == CT_DTYPE_U8 ? merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot)
-                                        : merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot);
+            return dtype == CT_DTYPE_U8 ? merge_typed<uint8_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot, clamp)
+                                        : merge_typed<uint16_t>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, fold, pivot, clamp);
         }
         case CT_DTYPE_F32: return merge_typed<float>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, false);
     }

@@ -29,6 +29,8 @@ struct MergeArgs {
     uint32_t flags;
 };
 
+constexpr float kPivotCondLimit = 8.0f;  // sum |terms| / result above which a wavefront repeats the batch about the mean
+
 template <typename T, int V>
 struct alignas(sizeof(T) * V) Packet {
     T v[V];

@@ -138,6 +138,10 @@ int ct_norm_constants(float max_code, float *hi, float *lo);
 int ct_index_constants(float max_code, int n_points, float *hi, float *lo);
 int ct_pivot_index_constants(float max_code, int n_points, uint32_t *index_mul, float *step);
 int ct_pivot_floor_constants(float max_code, int n_points, float *rcp_step);
+/*   ct_pivot_interval_constants  the general form of the above: table entry min(floor(u * *scale), last) equals the
+ *                            reference's LINEAR interval (lookup = 0) / LOOKUP sample (entry j -> sample (j + 1) >> 1,
+ *                            lookup = 1) for every code 0..dtype_max of the container, any max_code <= dtype_max, any L */
+int ct_pivot_interval_constants(float max_code, int n_points, int lookup, int dtype_max, float *scale);
 
 /* Diagnostics: a static string naming the kernel ct_hdr_merge_batch dispatches for these arguments. */
 const char *ct_hdr_merge_kernel_name(int32_t dtype, float max_code, int32_t interp, int32_t n_points, uint32_t flags);

@@ -101,6 +101,32 @@ def test_round_down_fma_interval_constants(lib, max_code, n_points, ok):
     assert np.array_equal(got, ref) and np.array_equal(got, u // step) and got.max() == n_points - 1
 
 
+@pytest.mark.parametrize("max_code,n_points,dtype_max", [(65535, 256, 65535), (4095, 256, 65535), (16383, 256, 65535),
+                                                         (1023, 256, 65535), (65535, 100, 65535), (65535, 1000, 65535),
+                                                         (65535, 772, 65535), (4095, 1024, 65535), (255, 256, 255),
+                                                         (255, 100, 255), (255, 64, 255), (255, 1024, 255)])
+@pytest.mark.parametrize("lookup", [0, 1])
+def test_pivot_interval_constants_every_code(lib, max_code, n_points, dtype_max, lookup):
+    """ct_pivot_interval_constants: min(floor(u * scale), last) -- one round-down FMA on the code -- is the reference's
+    LINEAR interval / LOOKUP sample for EVERY code the container can hold, also above max_code (12- and 14-bit data in a
+    uint16 container, which the reference clamps) and for LUT steps that are not a whole number of codes.  When the
+    function says yes the claim is re-checked here in numpy; a refusal only sends the merge to the generic kernel."""
+    r = ctypes.c_float()
+    lib.ct_pivot_interval_constants.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    rc = lib.ct_pivot_interval_constants(float(max_code), n_points, lookup, dtype_max, ctypes.byref(r))
+    top = n_points - 1
+    u = np.arange(dtype_max + 1)
+    s_ref = (u.astype(np.float32) / np.float32(max_code)) * np.float32(top)
+    if rc != 0:  # refusals happen where the reference's own two roundings move a code across an entry boundary
+        assert (max_code, n_points) not in ((65535, 256), (4095, 256), (16383, 256), (1023, 256), (255, 256))
+        return
+    got = np.minimum(np.floor(u.astype(np.float64) * np.float64(r.value)), 2 * top if lookup else top)  # exact product
+    if lookup:
+        assert np.array_equal((got + 1) // 2, np.clip(np.rint(s_ref), 0, top))
+    else:
+        assert np.array_equal(got, np.floor(np.clip(s_ref, 0, top)))
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from clair_torch_amd import _native
     monkeypatch.setattr(_native, "_lib", None)

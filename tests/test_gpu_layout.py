@@ -36,6 +36,9 @@ def test_merge_interleaved_equals_planar(dev, dtype, shape, mode):
     t = torch.tensor([0.001 * 2.0 ** k for k in range(n)], dtype=torch.float64)
     lut = torch.stack([torch.linspace(0, 1, 256) ** (1.8 + 0.3 * k) for k in range(c)]).to(dev)
     kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+    if mode == "catmull":
+        kw["reference_order"] = False  # the float64 closed-form oracle below is the comparand (the default CATMULL route
+        #                                carries the reference's float32 noise; its own tests are in test_gpu_merge.py)
     mean_p, std_p = ops.hdr_merge_batch(planar, t, **kw)
     nhwc = planar.permute(0, 2, 3, 1).contiguous()
     mean_i, std_i = ops.hdr_merge_batch(nhwc, t, layout="nhwc", **kw)
@@ -82,10 +85,7 @@ def test_linearize_interleaved_equals_planar(dev, dtype):
         x = oc.normalize_codes(np.ascontiguousarray(raw.cpu().numpy()[..., ::-1].transpose(0, 3, 1, 2)))
         lin_o, sd_o = oc.linearize_std(x, x * np.float32(0.05), lut.cpu().numpy(), mode)
         assert np.array_equal(lin_i.cpu().numpy(), lin_o)
-        if mode == "linear":
-            assert np.array_equal(sd_i.cpu().numpy(), sd_o)
-        else:
-            assert_parity(sd_i.cpu().numpy(), sd_o, rtol=1e-5, norm_tol=1e-6, what="nhwc_bgr catmull linearize std")
+        assert np.array_equal(sd_i.cpu().numpy(), sd_o)  # CATMULL too: the derivative in the reference's autograd order
         assert lin_i.shape == lin_p.shape and torch.equal(lin_i, lin_p) and torch.equal(sd_i, sd_p)
 
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 # bit; what is left against the recorded vectors is the last bit of torch's CPU exp (Sleef, 1 ULP: 1.1 % of its results are
 # not the correctly rounded ones), which the reference's own CATMULL chain amplifies to 1.07e-5 on the uint16 fixtures
 # (tests/test_oracle_golden.py::test_reference_uncertainty_depends_on_the_last_bit_of_exp) -- hence 1.1e-5 there.
-ELEM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 3e-5, "catmull": 1.1e-5}
+ELEM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 1e-5, "catmull": 1.1e-5}
 NORM_TOL = {"linear": 1e-5, "nomodel": 1e-5, "lookup": 1e-5, "catmull": 1e-5}
 
 
@@ -30,6 +30,31 @@ def dev():
     from clair_torch_amd import _native
     _native.load()  # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+def _closed_form(mode):
+    """CATMULL with uncertainties runs the reference-order kernel by default, which carries the reference's own float32
+    noise (up to 2e-5 against the closed form); the comparisons with the float64 closed-form oracle ask for the closed-form
+    kernels instead (CT_MERGE_CLOSED_FORM)."""
+    return dict(reference_order=False) if mode == "catmull" else {}
+
+
+def _pivot_proven(max_code, n_points, lookup, dtype_max):
+    """Does the host proof allow the code-domain table addressing of ct::merge_pivot_kernel for these arguments?"""
+    import ctypes
+    from clair_torch_amd import _native as nv
+    scale = ctypes.c_float()
+    fn = nv.load().ct_pivot_interval_constants
+    fn.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    return fn(float(max_code), int(n_points), int(lookup), int(dtype_max), ctypes.byref(scale)) == 0
+
+
+def _kernel_name(dtype, max_code, mode, n_points, first=True):
+    from clair_torch_amd import _native as nv
+    interp = {"lookup": nv.INTERP_LOOKUP, "linear": nv.INTERP_LINEAR, "catmull": nv.INTERP_CATMULL}[mode]
+    flags = (nv.MERGE_FIRST_BATCH if first else 0) | nv.MERGE_FINALIZE | nv.MERGE_STD_HINT | nv.MERGE_CLOSED_FORM
+    return nv.load().ct_hdr_merge_kernel_name(nv.DTYPE_U8 if dtype == "u8" else nv.DTYPE_U16, float(max_code), interp,
+                                              n_points, flags).decode()
 
 
 def _run_partition(ops, stack, t, part, dev, **kw):
@@ -48,9 +73,14 @@ def _run_batches(ops, stack, t, batches, dev, **kw):
     std_full = kw.pop("std", None)
     for bi, idx in enumerate(batches):
         contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
-        sel = slice(idx[0], idx[0] + len(idx)) if contiguous else torch.as_tensor(idx, device=stack.device)
-        res = ops.hdr_merge_batch(stack[sel].contiguous(), torch.from_numpy(t[idx]), state=st, finalize=bi == len(batches) - 1,
-                                  std=None if std_full is None else std_full[sel].contiguous(), **kw)
+        if contiguous:
+            sub = stack[idx[0]:idx[0] + len(idx)]
+            sub_std = None if std_full is None else std_full[idx[0]:idx[0] + len(idx)]
+        else:  # (torch has no CUDA gather for uint16: stack the images instead)
+            sub = torch.stack([stack[i] for i in idx])
+            sub_std = None if std_full is None else torch.stack([std_full[i] for i in idx])
+        res = ops.hdr_merge_batch(sub.contiguous(), torch.from_numpy(t[idx]), state=st, finalize=bi == len(batches) - 1,
+                                  std=None if sub_std is None else sub_std.contiguous(), **kw)
     return res
 
 
@@ -229,9 +259,51 @@ def test_merge_vs_oracle_ragged_shapes(dev, shape, dtype):
         for part in ([n], [2, n - 2]):
             mean_o, std_o = oc.hdr_merge(x, sd, t, lut, mode, True, part)
             mean, std = _run_partition(ops, stack, t, part, dev, lut=lut_d, interp=mode, gaussian_weight=True,
-                                       std=torch.from_numpy(sd).to(dev))
+                                       std=torch.from_numpy(sd).to(dev), **_closed_form(mode))
             assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"{mode} mean")
             assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"{mode} std")
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 37, 53), (7, 1, 64, 40), (20, 3, 8, 32)])
+@pytest.mark.parametrize("dtype", ["u16", "f32"])
+@pytest.mark.parametrize("mode", ["catmull", "linear", "lookup"])
+def test_merge_reference_order_kernel_ragged_shapes(dev, shape, dtype, mode):
+    """ct_merge_exact.hip on odd shapes, 20 exposures (torch.sum's 16-row cascade), streamed state: bit for bit the
+    float32-order emulation on every element whose column lies in torch.sum's vectorised blocks (the first 32 * (Q // 32)
+    flattened columns; the last Q % 32 go through a differently associated sum on the CPU, tests/test_oracle_golden.py), and
+    1e-5 everywhere."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    from oracle import eager_torch as oe
+    torch.set_num_threads(1)  # the reference's column blocks start at the beginning of each thread's chunk
+    n, c, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    t = 0.002 * 2.0 ** (np.arange(n) / 3.0)
+    lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(2.0 + 0.2 * k) for k in range(c)])
+    if dtype == "f32":
+        x = rng.random((n, c, h, w), dtype=np.float32)
+        stack = torch.from_numpy(x).to(dev)
+    else:
+        codes = rng.integers(0, 65536, size=shape).astype(np.uint16)
+        x = oc.normalize_codes(codes)
+        stack = torch.from_numpy(codes).to(dev)
+    sd = (0.001 + 0.05 * rng.random(shape)).astype(np.float32)
+    exact_exp = lambda v: torch.exp(v.double()).float()   # noqa: E731
+    q = c * h * w
+    main = (q // 32) * 32
+    for part in ([n], [2, n - 2]):
+        batches, k = [], 0
+        for b in part:
+            batches.append(list(range(k, k + b)))
+            k += b
+        mean_e, std_e = oe.merge_stack_reference_order(torch.from_numpy(x), torch.from_numpy(sd), torch.from_numpy(t),
+                                                       torch.from_numpy(lut), mode, True, batches, exp=exact_exp)
+        mean, std = _run_batches(ops, stack, t, batches, dev, lut=torch.from_numpy(lut).to(dev), interp=mode,
+                                 gaussian_weight=True, std=torch.from_numpy(sd).to(dev), reference_order=True)
+        got, want = std.cpu().numpy().reshape(-1), std_e.numpy().reshape(-1)
+        assert np.array_equal(got[:main], want[:main]), (mode, part)
+        assert_parity(got, want, rtol=1e-5, norm_tol=1e-6, what=f"reference order {mode} std (with the tail columns)")
+        assert_parity(mean.cpu().numpy(), mean_e.numpy(), rtol=1e-13, norm_tol=1e-14, what=f"reference order {mode} mean")
 
 
 def test_merge_tiles_equal_whole(dev):
@@ -278,7 +350,7 @@ def test_merge_packets_crossing_channel_planes(dev, c, h, w, dtype):
     sd = (0.05 * x).astype(np.float32)
     lut_d = torch.from_numpy(lut).to(dev)
     for mode in ("linear", "catmull", "lookup"):
-        kw = dict(lut=lut_d, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+        kw = dict(lut=lut_d, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05, **_closed_form(mode))
         mean, std = ops.hdr_merge_batch(stack, torch.from_numpy(t), **kw)
         mean_o, std_o = oc.hdr_merge(x, sd, t, lut, mode, True, [n])
         assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"{mode} mean")
@@ -376,9 +448,13 @@ def test_merge_unusual_lut_sizes(dev, n_points, dtype):
     t = 0.001 * 2.0 ** np.arange(n)
     lut = np.stack([np.linspace(0, 1, n_points, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
     for mode in ("linear", "lookup", "catmull"):
+        # LINEAR and LOOKUP on raw codes run the pivoted code-domain kernel for ANY LUT length the host proof accepts
+        # (steps that are not a whole number of codes included); CATMULL and refused lengths the generic pivoted kernel
+        name = _kernel_name(dtype, hi - 1, mode, n_points)
+        assert ("merge_pivot_kernel" in name) == (mode != "catmull" and _pivot_proven(hi - 1, n_points, mode == "lookup", hi - 1)), name
         mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, mode, True)
         mean, std = ops.hdr_merge_batch(torch.from_numpy(codes).to(dev), torch.from_numpy(t), lut=torch.from_numpy(lut).to(dev),
-                                        interp=mode, std_mode="multiplier", std_value=0.05)
+                                        interp=mode, std_mode="multiplier", std_value=0.05, **_closed_form(mode))
         assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"L={n_points} {mode} mean")
         assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"L={n_points} {mode} std")
 
@@ -399,10 +475,7 @@ def test_merge_whole_step_lut_sizes_on_the_typed_load_kernel(dev, dtype, n_point
     name = nv.load().ct_hdr_merge_kernel_name(nv.DTYPE_U8 if dtype == "u8" else nv.DTYPE_U16, float(maxc), nv.INTERP_LINEAR,
                                               n_points, nv.MERGE_FIRST_BATCH | nv.MERGE_FINALIZE).decode()
     # ... unless the reference's own float32 index is not code // step (L = 772: the proof refuses, the generic kernel runs)
-    import ctypes
-    rcp = ctypes.c_float()
-    nv.load().ct_pivot_floor_constants.argtypes = [ctypes.c_float, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
-    proven = nv.load().ct_pivot_floor_constants(float(maxc), n_points, ctypes.byref(rcp)) == 0
+    proven = _pivot_proven(maxc, n_points, False, maxc)
     assert proven == (n_points != 772)
     assert ("merge_pivot_kernel" in name and "typed buffer loads" in name) == proven
     rng = np.random.default_rng(1000 * n_points + shape[1])
@@ -438,10 +511,12 @@ def test_codes_above_max_code_are_clamped_like_the_reference(dev, mode):
     x = (codes.astype(np.float32) / np.float32(4095.0)).astype(np.float32)
     t = 0.001 * 2.0 ** np.arange(n)
     lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
+    # Normalize(4095) on uint16: the pivoted code-domain kernel with the clamp (one v_min per sample), not the generic one
+    assert ("merge_pivot_kernel" in _kernel_name("u16", 4095, mode, 256)) == (mode != "catmull")
     for part in ([n], [2, 4]):
         mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, mode, True, part)
         mean, std = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, lut=torch.from_numpy(lut).to(dev),
-                                   interp=mode, std_mode="multiplier", std_value=0.05, max_code=4095.0)
+                                   interp=mode, std_mode="multiplier", std_value=0.05, max_code=4095.0, **_closed_form(mode))
         assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"max_code 4095 {mode} mean")
         assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"max_code 4095 {mode} std")
 
@@ -475,3 +550,92 @@ def test_band_statistics_match_torch_reductions(dev, shape, with_std):
                             torch.minimum(a[3], b[3]), torch.maximum(a[4], b[4]), a[5] + b[5]])
         assert torch.equal(comb[[0, 1, 3, 4]], out[[0, 1, 3, 4]]) and torch.allclose(comb[[2, 5]], out[[2, 5]], rtol=1e-13, atol=1e-13)
 
+
+
+class _RetryCounter:
+    """ct_merge_set_retry_counter around a block: counts the wavefronts of ct::merge_pivot_kernel that repeated a batch."""
+
+    def __init__(self, dev):
+        self.buf = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def __enter__(self):
+        from clair_torch_amd import _native as nv
+        import ctypes
+        nv.load().ct_merge_set_retry_counter.argtypes = [ctypes.c_void_p]
+        nv.load().ct_merge_set_retry_counter(ctypes.c_void_p(self.buf.data_ptr()))
+        return self
+
+    def __exit__(self, *exc):
+        from clair_torch_amd import _native as nv
+        torch.cuda.synchronize()
+        nv.load().ct_merge_set_retry_counter(None)
+
+    def value(self):
+        torch.cuda.synchronize()
+        return int(self.buf.item())
+
+
+@pytest.mark.parametrize("dtype", ["u8", "u16"])
+@pytest.mark.parametrize("kind", ["plateau_then_rise", "jump"])
+def test_pivot_kernel_exact_offset_staging_on_steep_luts(dev, dtype, kind):
+    """ADVICE r2: the `rough` staging of ct::merge_pivot_kernel ({g[i], S} entries and the exactly formed offset
+    code - i * step, taken when |A| > 64 max|g| somewhere): a LUT with ~100 leading zeros and a steep rise, and one with a
+    jump, L = 256, uint8 and uint16 -- against the float64-moment kernel and the float64 oracle."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(77)
+    n, c, h, w = 6, 3, 16, 32
+    hi = 256 if dtype == "u8" else 65536
+    codes = rng.integers(0, hi, size=(n, c, h, w)).astype(np.uint8 if dtype == "u8" else np.uint16)
+    x = oc.normalize_codes(codes)
+    t = 0.001 * 2.0 ** np.arange(n)
+    grid = np.linspace(0, 1, 256, dtype=np.float64)
+    if kind == "plateau_then_rise":
+        rows = [np.where(grid < 100 / 255, 0.0, ((grid - 100 / 255) / (155 / 255)) ** p) for p in (3.0, 4.0, 5.0)]
+    else:
+        rows = [grid ** p * np.where(np.arange(256) >= 200, 9.0, 1.0) for p in (2.2, 2.4, 2.6)]
+    lut = np.stack(rows).astype(np.float32)
+    assert "merge_pivot_kernel" in _kernel_name(dtype, hi - 1, "linear", 256)
+    lut_d = torch.from_numpy(lut).to(dev)
+    for part in ([n], [2, 4]):
+        kw = dict(lut=lut_d, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+        mean, std = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, **kw)
+        mean_f, std_f = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, force_f64_moments=True, **kw)
+        mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, "linear", True, part)
+        assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what=f"{kind} mean vs oracle")
+        assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what=f"{kind} std vs oracle")
+        assert_parity(std.cpu().numpy(), std_f.cpu().numpy(), rtol=1e-5, norm_tol=1e-5, what=f"{kind} std vs float64 moments")
+        assert_parity(mean.cpu().numpy(), mean_f.cpu().numpy(), rtol=1e-5, norm_tol=1e-6, what=f"{kind} mean vs float64 moments")
+
+
+@pytest.mark.parametrize("dtype", ["u8", "u16"])
+def test_pivot_kernel_retry_pass_is_taken_and_exact(dev, dtype):
+    """ADVICE r2: the ill-conditioned-pivot repeat of ct::merge_pivot_kernel.  A stack whose MIDDLE exposure (the first
+    batch's pivot seed) is black or saturated while the others are consistent, then a second streamed batch far from the
+    running mean: the retry counter must move, and the result must still match the float64-moment kernel and the oracle."""
+    from clair_torch_amd import ops
+    from oracle import ct_oracle as oc
+    rng = np.random.default_rng(123)
+    n, c, h, w = 8, 3, 16, 64
+    maxc = 255 if dtype == "u8" else 65535
+    t = 0.001 * 2.0 ** np.arange(n)
+    e = rng.random((c, h, w)) * (2.0 / np.sqrt(t[0] * t[-1]))
+    lin = np.clip(e[None] * t[:, None, None, None], 0.0, 1.0)
+    codes = np.rint(lin ** (1 / 2.2) * maxc).astype(np.uint8 if dtype == "u8" else np.uint16)
+    codes[n // 2, :, :, : w // 2] = 0          # first batch [n]: pivot seed black on the left half ...
+    codes[n // 2, :, :, w // 2:] = maxc        # ... and saturated on the right half
+    codes[5:] = np.rint(np.clip(codes[5:].astype(np.float64) * 0.2, 0, maxc)).astype(codes.dtype)   # second batch far from the mean
+    x = oc.normalize_codes(codes)
+    lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(p) for p in (2.2, 2.4, 2.6)])
+    lut_d = torch.from_numpy(lut).to(dev)
+    kw = dict(lut=lut_d, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+    for part in ([n], [5, 3]):
+        with _RetryCounter(dev) as counter:
+            mean, std = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, **kw)
+            retried = counter.value()
+        assert retried > 0, f"the retry pass never ran (partition {part})"
+        mean_f, std_f = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, force_f64_moments=True, **kw)
+        mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, "linear", True, part)
+        assert_parity(mean.cpu().numpy(), mean_o, rtol=1e-5, norm_tol=1e-6, what="retry mean vs oracle")
+        assert_parity(std.cpu().numpy(), std_o, rtol=1e-5, norm_tol=1e-5, what="retry std vs oracle")
+        assert_parity(std.cpu().numpy(), std_f.cpu().numpy(), rtol=1e-5, norm_tol=1e-5, what="retry std vs float64 moments")

@@ -71,7 +71,7 @@ void launch_v(const MergeArgs &a0, hipStream_t s)
     MergeArgs a = a0;
     const uint32_t vecs = a.q_count / V, grid = (vecs + kBlock - 1) / kBlock;
     const size_t lds = (size_t)a.channels * a.n_points * lut_entry_bytes(CT_INTERP_LINEAR) + 2 * sizeof(float) * (size_t)a.batch;
-    hipLaunchKernelGGL((merge_kernel<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, true, PF>), dim3(grid), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((merge_kernel<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, true, PF, false>), dim3(grid), dim3(kBlock), lds, s, a);
 }
 
 static PivotArgs g_px;
@@ -80,7 +80,7 @@ void launch_pivot_v(const MergeArgs &a0, hipStream_t s)
 {
     MergeArgs a = a0;
     a.q_count = (a.q_count / (kBlock * V)) * (kBlock * V);
-    int rc = launch_pivot<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD>(a, g_px, s);
+    int rc = launch_pivot<uint16_t, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, STD, false>(a, g_px, s);
     if (rc != CT_OK) { printf("launch_pivot rc %d\n", rc); exit(1); }
 }
 
@@ -137,7 +137,7 @@ int main(int argc, char **argv)
 
     if (ct_pivot_index_constants(65535.0f, 256, &g_px.index_mul, &g_px.step) != CT_OK) { printf("pivot index refused\n"); return 1; }
     if (ct_pivot_floor_constants(65535.0f, 256, &g_px.index_rcp) != CT_OK) { printf("pivot floor constants refused\n"); return 1; }
-    g_px.probe = N / 2;
+    g_px.probe = N / 2; g_px.max_code = 65535.0f; g_px.n_entries = 256; g_px.tf_max = kFloorMagic + 255.0f;
     unsigned long long *retries; CK(hipMalloc(&retries, 8)); CK(hipMemset(retries, 0, 8));
     g_px.retry_count = retries;
     double *mean2; float *std2; double *acc;
