@@ -1292,13 +1292,16 @@ static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_poin
     return true;
 }
 
-// CATMULL with uncertainties follows the reference's float32 autograd order by default (ct_merge_exact.hip: the closed form
-// differs from the reference by the reference's own cancellation noise, up to 2e-5); CT_MERGE_REFERENCE_ORDER asks for
-// that path in any mode, CT_MERGE_CLOSED_FORM keeps the fast closed-form kernels for CATMULL too.
+// LOOKUP and CATMULL with uncertainties follow the reference's float32 autograd order by default (ct_merge_exact.hip):
+// their reference results are dominated by float32 cancellation -- CATMULL in the cubic-basis backward, LOOKUP (whose
+// variance is the weight path alone) in y_n - m_b with m_b formed from the float32-rounded sum of weights -- so a closed
+// form, however accurate, differs from the reference by the reference's own noise (up to 2e-5 / 4e-5 on single elements).
+// CT_MERGE_REFERENCE_ORDER asks for that path in any mode, CT_MERGE_CLOSED_FORM keeps the fast closed-form kernels.
 static bool merge_uses_reference_order(int interp, int std_mode, uint32_t flags)
 {
     if (flags & CT_MERGE_REFERENCE_ORDER) return true;
-    return interp == CT_INTERP_CATMULL && std_mode != CT_STD_NONE && !(flags & (CT_MERGE_CLOSED_FORM | CT_MERGE_F64_MOMENTS));
+    return (interp == CT_INTERP_CATMULL || interp == CT_INTERP_LOOKUP) && std_mode != CT_STD_NONE &&
+           !(flags & (CT_MERGE_CLOSED_FORM | CT_MERGE_F64_MOMENTS));
 }
 
 // Which kernel ct_hdr_merge_batch dispatches for these arguments (bench.py records it next to its numbers).

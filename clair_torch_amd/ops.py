@@ -108,7 +108,8 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
     float32 one would run (tests compare the two).
     ``reference_order``: True = evaluate the uncertainty in the reference's own float32 autograd order
     (CT_MERGE_REFERENCE_ORDER: two passes, slower, reproduces the reference's rounding); False = closed-form kernels in
-    every mode (CT_MERGE_CLOSED_FORM); None = the library's default (reference order for CATMULL with uncertainties only).
+    every mode (CT_MERGE_CLOSED_FORM); None = the library's default (reference order for LOOKUP / CATMULL with
+    uncertainties, closed form otherwise).
     """
     _check_stack(stack)
     b = stack.shape[0]

@@ -65,9 +65,9 @@ extern "C" {
 #define CT_MERGE_MEAN_OUT_F32 4u /* mean_out is float32 instead of the reference's float64 */
 #define CT_MERGE_F64_MOMENTS 8u  /* diagnostic: keep the float64-moment kernel where the pivoted float32 one would run */
 #define CT_MERGE_REFERENCE_ORDER 16u /* evaluate the uncertainty in the reference's own float32 autograd order (two passes,
-                                        float64 exp / divisions; ct_merge_exact.hip).  Default for CATMULL with uncertainties,
-                                        whose reference result is dominated by float32 cancellation in the cubic-basis backward */
-#define CT_MERGE_CLOSED_FORM 32u     /* keep the fast closed-form kernels for CATMULL with uncertainties as well */
+                                        float64 exp / divisions; ct_merge_exact.hip).  Default for LOOKUP and CATMULL with
+                                        uncertainties, whose reference results are dominated by float32 cancellation */
+#define CT_MERGE_CLOSED_FORM 32u     /* keep the fast closed-form kernels for LOOKUP / CATMULL with uncertainties as well */
 #define CT_MERGE_STD_HINT 64u        /* ct_hdr_merge_kernel_name only: uncertainties are propagated */
 
 /* Memory layout of one image of a stack.  Outputs and state are always planar (C, H, W) like the reference's tensors.

@@ -36,8 +36,8 @@ def test_merge_interleaved_equals_planar(dev, dtype, shape, mode):
     t = torch.tensor([0.001 * 2.0 ** k for k in range(n)], dtype=torch.float64)
     lut = torch.stack([torch.linspace(0, 1, 256) ** (1.8 + 0.3 * k) for k in range(c)]).to(dev)
     kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05)
-    if mode == "catmull":
-        kw["reference_order"] = False  # the float64 closed-form oracle below is the comparand (the default CATMULL route
+    if mode in ("catmull", "lookup"):
+        kw["reference_order"] = False  # the float64 closed-form oracle below is the comparand (the default LOOKUP / CATMULL route
         #                                carries the reference's float32 noise; its own tests are in test_gpu_merge.py)
     mean_p, std_p = ops.hdr_merge_batch(planar, t, **kw)
     nhwc = planar.permute(0, 2, 3, 1).contiguous()
