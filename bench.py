@@ -75,6 +75,68 @@ def cpu_baseline_merge(n_exp, stops, seconds=12.0, tile=512):
                       f"oracle/eager_torch.merge_stack incl. autograd variance, {el:.1f} s"}
 
 
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def c5_strong_block(args, rank, world, dev, ops=None, make_stack=None):
+    """BASELINE config C5 as stated, inside the driver's `--gpus N` line: ONE --global-size^2 x 3 image (default 8192)
+    cut into `world` row bands, every timed step = merge + uncertainty of the rank's band (ct_hdr_merge_batch with the
+    global geometry), the per-band statistics in one fused pass (ct_band_stats) and their all_gather over RCCL.  Fixed
+    total work: value(N) / value(1) is the speed-up.  Barrier + synchronize on both sides, max over ranks, per-rank times
+    gathered.  `ops` / `make_stack`: injection points for the 2-rank gloo test (tests/test_distributed_gloo.py), which
+    drives exactly this function with CPU stand-ins for the two kernels."""
+    if ops is None:
+        from clair_torch_amd import ops
+    if make_stack is None:
+        from clair_torch_amd.datasets import synthetic_exposure_stack as make_stack
+    n_exp, c = args.exposures, 3
+    h_global = w = args.global_size
+    if h_global % world:
+        return {"skipped": f"{h_global} rows do not split into {world} equal bands"}
+    h = h_global // world
+    lut = make_lut(dev)
+    codes, exposures = make_stack(n_exp, c, h_global, w, bits=16, stops_per_step=0.25, seed=1240, device=dev,
+                                  row_range=(rank * h, (rank + 1) * h))
+    t_dev = torch.tensor(exposures, dtype=torch.float64, device=dev)
+    tile = ops.TileGeometry(h_global=h_global, row_offset=rank * h)
+    kw = dict(lut=lut, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05, tile=tile)
+
+    def step():
+        mean, std = ops.hdr_merge_batch(codes, t_dev, **kw)
+        return gather_stats(ops.band_stats(mean, std), world)
+
+    for _ in range(args.warmup):
+        gathered = step()
+    barrier(world)
+    _sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    _sync(dev)
+    mine = time.perf_counter() - t0
+    barrier(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    per_rank = [mine]
+    if _dist_on():
+        box = [None] * world
+        torch.distributed.all_gather_object(box, mine)
+        per_rank = [float(v) for v in box]
+    px = h_global * w
+    bytes_alg = (n_exp * c * px * 2 + c * px * 12 + c * px * 12) / world  # per GPU: stack read, outputs written, outputs re-read by the statistics
+    return {
+        "workload": f"C5: {n_exp}-exposure {h_global}x{w}x3 uint16 image in {world} row band(s) of {h} rows, merge+uncertainty, "
+                    "per-band statistics (ct_band_stats) all_gathered inside every timed step",
+        "scaling": "strong", "value": round(px * args.steps / elapsed / 1e6, 1), "unit": "MPix/s",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step_per_rank": {"min": round(min(per_rank) / args.steps * 1e3, 4), "max": round(max(per_rank) / args.steps * 1e3, 4)},
+        "world_seen": torch.distributed.get_world_size() if _dist_on() else 1,
+        "bands_gathered": int(gathered.shape[0]), "finite": bool(torch.isfinite(gathered).all()),
+        "hbm_frac_per_gpu": round(bytes_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+    }
+
+
 def run_merge(args, rank, world, dev):
     """C2 per GPU (weak scaling, the default) or C5's own geometry (--scaling strong: one global 8192x8192x3 image cut
     into `world` row bands of 8192 / world rows, per-band statistics gathered over RCCL inside every timed step)."""
@@ -116,6 +178,12 @@ def run_merge(args, rank, world, dev):
         kw.update(std_mode="none")
     if args.f64_moments:
         kw.update(force_f64_moments=True)
+    if args.layout != "nchw":
+        # the layout north_star names: (N, H, W, C) as OpenCV decodes it (BGR: channel order reversed on the fly)
+        codes = (codes.flip(1) if args.layout == "nhwc_bgr" else codes).permute(0, 2, 3, 1).contiguous()
+        if "std" in kw:
+            kw["std"] = (kw["std"].flip(1) if args.layout == "nhwc_bgr" else kw["std"]).permute(0, 2, 3, 1).contiguous()
+        kw.update(layout=args.layout)
 
     def band_stats(mean, std):
         # per channel: min, max, sum of the mean and of the std -- one fused pass (ct_band_stats; torch's reductions took
@@ -177,7 +245,8 @@ def run_merge(args, rank, world, dev):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{name}: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU, "
+        "config": {"workload": f"{name}: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU"
+                               f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, "
                                f"merge{'' if args.std == 'none' else '+uncertainty'} (LINEAR ICRF 3x256, Gaussian weights, "
                                f"sigma: {args.std}, float64 mean + float32 std out)"
                                + (", per-band statistics all_gather (RCCL) inside every step" if strong else ""),
@@ -201,8 +270,15 @@ def run_merge(args, rank, world, dev):
             "launches": 100, "after_launches": steady[1],
             "note": "same launches, measured after the timed region once the clock transient of the first ~40 launches "
                     "has passed; not part of value / ms_per_step / frac"}
+    if world > 1 and not strong:
+        # the driver's multi-GPU line is weak scaling (above); BASELINE's configuration C5 -- one 8192^2 image in N bands,
+        # statistics gather inside every step -- rides in the same JSON line
+        codes = mean = std = gathered = None   # (the stack is captured by step(): rebind, then release)
+        torch.cuda.empty_cache()
+        block = c5_strong_block(args, rank, world, dev)
+        out["c5_strong"] = block
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        del codes
+        codes = None
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline_merge(n_exp, 0.25, args.cpu_seconds)
     return out
@@ -216,8 +292,10 @@ def run_linearize(args, rank, world, dev):
     if args.streamed:
         return run_linearize_streamed(args, dev)
     frames = torch.randint(0, 65536, (args.frames, 3, 1080, 1920), device=dev, dtype=torch.int32).to(torch.uint16)
+    if args.layout != "nchw":
+        frames = (frames.flip(1) if args.layout == "nhwc_bgr" else frames).permute(0, 2, 3, 1).contiguous()
     lut = make_lut(dev)
-    step = lambda: ops.linearize_frames(frames, lut, "linear", std_mode="multiplier", std_value=0.05)  # noqa: E731
+    step = lambda: ops.linearize_frames(frames, lut, "linear", std_mode="multiplier", std_value=0.05, layout=args.layout)  # noqa: E731
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -236,7 +314,8 @@ def run_linearize(args, rank, world, dev):
             "value": round(args.frames * args.steps / elapsed, 1), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C4 (kernel-only): {args.frames} resident 1920x1080x3 uint16 frames per launch, ct_linearize_std"},
+            "config": {"workload": f"C4 (kernel-only): {args.frames} resident 1920x1080x3 uint16 frames per launch"
+                                   f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, ct_linearize_std"},
             "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic("linearize_c4") if args.frames == 64 else None}}
@@ -509,6 +588,8 @@ def main():
                          "--global-size^2 image cut into N row bands with the per-band statistics gather in every step")
     ap.add_argument("--global-size", type=int, default=8192, help="--scaling strong: rows = columns of the global image")
     ap.add_argument("--f64-moments", action="store_true", help="merge: time the float64-moment kernel (round-1 path)")
+    ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc", "nhwc_bgr"],
+                    help="merge / linearize: memory order of the stack (nhwc = as decoded, nhwc_bgr = OpenCV's channel order)")
     ap.add_argument("--exposures", type=int, default=32)
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--width", type=int, default=4096)

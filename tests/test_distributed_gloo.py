@@ -292,3 +292,60 @@ def _halo_worker(rank, world, port, out_dir):
 def test_dark_field_halo_exchange_three_ranks(tmp_path):
     mp.spawn(_halo_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
     assert all((tmp_path / f"halo_ok{r}").exists() for r in range(3))
+
+
+# ---- bench.py's c5_strong block (what the driver's `--gpus N` line carries for N > 1) on 2 gloo ranks -----------------
+def _c5_worker(rank, world, port, out_dir):
+    import argparse
+    import types
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from clair_torch_amd import ops as real_ops
+        from clair_torch_amd.datasets import synthetic_exposure_stack
+        from oracle import ct_oracle as oc
+        seen = {}
+
+        def fake_merge(stack, exposures, *, lut, interp, gaussian_weight, std_mode, std_value, tile):
+            # CPU stand-in for ct_hdr_merge_batch (oracle arithmetic with the GLOBAL geometry the block must pass)
+            assert tile.h_global == 64 and tile.row_offset == rank * 32 and stack.shape == (6, 3, 32, 64)
+            x = oc.normalize_codes(stack.numpy())
+            mean, std = oc.hdr_merge(x, x * np.float32(std_value), exposures.numpy(), lut.numpy(), interp, gaussian_weight,
+                                     tile=(tile.h_global, tile.row_offset))
+            seen["mean"], seen["std"] = mean, std
+            return torch.from_numpy(mean), torch.from_numpy(std)
+
+        def fake_band_stats(mean, std):
+            m, s = mean.reshape(3, -1), std.reshape(3, -1).double()
+            return torch.stack([m.min(1).values, m.max(1).values, m.sum(1), s.min(1).values, s.max(1).values, s.sum(1)])
+
+        fake_ops = types.SimpleNamespace(hdr_merge_batch=fake_merge, band_stats=fake_band_stats, TileGeometry=real_ops.TileGeometry)
+        args = argparse.Namespace(exposures=6, global_size=64, steps=2, warmup=1)
+        block = bench.c5_strong_block(args, rank, world, "cpu", ops=fake_ops, make_stack=synthetic_exposure_stack)
+        assert block["scaling"] == "strong" and block["world_seen"] == 2 and block["bands_gathered"] == 2 and block["finite"]
+        assert block["steps"] == 2 and block["value"] > 0 and block["ms_per_step"] > 0
+        assert block["ms_per_step_per_rank"]["min"] <= block["ms_per_step_per_rank"]["max"] <= block["ms_per_step"] * 1.0001
+        assert "64x64x3" in block["workload"] and "2 row band(s) of 32 rows" in block["workload"]
+        # the two bands are the two halves of ONE image: the whole-image merge on one process gives the same rows
+        whole, exposures = synthetic_exposure_stack(6, 3, 64, 64, bits=16, stops_per_step=0.25, seed=1240)
+        xw = oc.normalize_codes(whole.numpy())
+        lut = bench.make_lut("cpu").numpy()
+        m_w, s_w = oc.hdr_merge(xw, xw * np.float32(0.05), np.asarray(exposures), lut, "linear", True)
+        assert np.array_equal(seen["mean"], m_w[:, rank * 32:(rank + 1) * 32]) and np.array_equal(seen["std"], s_w[:, rank * 32:(rank + 1) * 32])
+        # odd split: reported, not crashed
+        args3 = argparse.Namespace(exposures=6, global_size=63, steps=1, warmup=0)
+        assert "skipped" in bench.c5_strong_block(args3, rank, world, "cpu", ops=fake_ops, make_stack=synthetic_exposure_stack)
+        open(os.path.join(out_dir, f"c5_ok{rank}"), "w").write(str(block))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_c5_strong_block_two_ranks(tmp_path):
+    """`bench.py --gpus N` (N > 1) adds a `c5_strong` block to its JSON line: BASELINE configuration C5 as stated -- one
+    global image in N row bands, merge + per-band statistics + all_gather inside every timed step.  The same function
+    the bench calls, on 2 gloo ranks with CPU stand-ins for the two kernels and a 64x64 global image."""
+    mp.spawn(_c5_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "c5_ok0").exists() and (tmp_path / "c5_ok1").exists()
