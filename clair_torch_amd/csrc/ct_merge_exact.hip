@@ -62,6 +62,24 @@ struct TorchRowSum {
 // the correctly rounded value for 98.9 % of arguments; the other 1.1 % are the irreducible difference to the recorded vectors.
 __device__ __forceinline__ float exp_correctly_rounded(float v) { return (float)exp((double)v); }
 
+// Correctly rounded float32 square root.  hipcc's own expansion (__fsqrt_rn / sqrtf: v_sqrt_f32 plus a one-step fix-up)
+// was measured 1 ULP low on 17 % of the variances of the recorded fixtures on gfx950 (true root up to 0.86 ULP above the
+// returned value; tools/debug/exact_dump2.py), so the candidate from the float64 root is checked here against the exact
+// rounding boundaries: a midpoint of two neighbouring floats has 25 significant bits, its square 50 -- exact in float64.
+__device__ __forceinline__ float sqrt_correctly_rounded(float v)
+{
+    if (!(v > 0.0f) || v > 3.0e38f) return __builtin_sqrtf(v);  // zeros, negatives (NaN), infinities, NaN: the plain result
+    float s = (float)__builtin_sqrt((double)v);
+    const double vd = (double)v;
+    const float up = __uint_as_float(__float_as_uint(s) + 1u), dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const double m_up = 0.5 * ((double)s + (double)up), m_dn = 0.5 * ((double)s + (double)dn);
+    if (m_up * m_up < vd)
+        s = up;
+    else if (m_dn * m_dn > vd)
+        s = dn;
+    return s;
+}
+
 template <typename T, int V, int INTERP, int WEIGHT, int STD>
 __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const MergeArgs a)
 {
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
                 static_cast<float *>(a.mean_out)[qp[e]] = (float)mean[e];
             else
                 static_cast<double *>(a.mean_out)[qp[e]] = mean[e];
-            if constexpr (kHasStd) a.std_out[qp[e]] = __fsqrt_rn(var_o[e]);   // hdr_merge.py:155
+            if constexpr (kHasStd) a.std_out[qp[e]] = sqrt_correctly_rounded(var_o[e]);   // hdr_merge.py:155
         }
     }
 }

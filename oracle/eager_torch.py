@@ -232,16 +232,17 @@ def masked_weighted_mean_std(values, weights, mask, eps=1e-8):
     return mean.squeeze((2, 3)), std.squeeze((2, 3))
 
 
-def linearity_statistics(vals, stds, exposures, lut, mode, ratio_threshold, lo, hi, use_relative, use_unc_weight):
+def linearity_statistics(vals, stds, exposures, lut, mode, ratio_threshold, lo, hi, use_relative, use_unc_weight, forward=None):
     """Body shared by train_icrf (clair_torch/training/icrf_training.py:105-136) and measure_linearity
     (clair_torch/inference/measure_linearity.py:44-72).  ``lut`` may require grad (training) or be None.
+    ``forward``: replaces icrf_forward(x, lut, mode) (linearity_lut_grad_f64 passes one built on explicit LUT taps).
     Returns (ratio, spatial mean (P,C), spatial std, spatial error|None)."""
     i, j, r = exposure_pairs(exposures.to(torch.float64), ratio_threshold)
     xi, xj = vals[i], vals[j]
     mask = (xi >= lo) & (xi <= hi) & (xj >= lo) & (xj <= hi)                  # general_functions.py:302
     gw = gaussian_weight(xi, 10.0) + gaussian_weight(xj, 10.0)               # losses.py:208-235
     x = vals.clone().requires_grad_(stds is not None or (lut is not None and lut.requires_grad))
-    lin = icrf_forward(x, lut, mode) if lut is not None else x
+    lin = (forward(x) if forward is not None else icrf_forward(x, lut, mode)) if lut is not None else x
     if stds is not None:
         g = torch.autograd.grad(lin, x, torch.ones_like(lin), retain_graph=True)[0]
         lsd = (g * stds).abs()
@@ -290,6 +291,53 @@ def training_loss(vals, stds, exposures, lut, mode=LINEAR, ratio_threshold=0.25,
     lin_loss = torch.sqrt((sp ** 2).sum(dim=0))
     mono, rng, endp, smooth = curve_penalties(lut)
     return lin_loss + alpha * mono + beta * rng + gamma * endp + delta * smooth, lin_loss, sp
+
+
+def linearity_lut_grad_f64(vals, stds, exposures, lut, mode=LINEAR, ratio_threshold=0.25, lo=1 / 255, hi=254 / 255,
+                           use_relative=True, use_unc_weight=False):
+    """The LUT gradient of the training loss's linearity term with a DETERMINISTIC accumulation: the comparand for the
+    backward kernels.  The reference's gradient reaches the (C, L) LUT through the backward of ``icrf[rows, idx]``, a
+    float32 index_put whose accumulation order depends on the CPU thread count (2.6e-6 norm-wise between 3 and 8
+    threads on a uint8 CATMULL case).  Here the LUT taps are explicit leaves: out = sum_k basis_k * tap_k with the same
+    float32 arithmetic as icrf_forward, autograd delivers d loss / d tap_k per sample exactly as it would hand them to
+    index_put, and the scatter into the (C, L) bins is done in float64 (order-independent to 1e-15).
+    Returns (linearity loss (C,), spatial means (P,C), LUT gradient (C,L) float64)."""
+    n, c, h, w = vals.shape
+    size = lut.shape[1]
+    top = size - 1
+    lut = lut.detach()
+    rows = torch.arange(c).repeat(n * h * w)
+    taps, tap_index = [], []
+
+    def forward(x):
+        def take(ix):
+            tap_index.append(ix.reshape(-1))
+            taps.append(lut[rows, ix.reshape(-1)].reshape(n, c, h, w).clone().requires_grad_(True))
+            return taps[-1]
+
+        if mode == LOOKUP:
+            raise ValueError("LOOKUP carries no LUT gradient in the reference")
+        if mode == LINEAR:
+            s = (x * top).clamp(0, top)
+            i0 = s.floor().long()
+            fr = s - i0.float()
+            return take(i0) * (1.0 - fr) + take((i0 + 1).clamp(0, top)) * fr
+        s = (x * top).clamp(0, top)
+        i0 = s.floor().long()
+        t = (s - i0.float()).clamp(0, 1)
+        t2 = t * t
+        t3 = t2 * t
+        basis = (-0.5 * t3 + t2 - 0.5 * t, 1.5 * t3 - 2.5 * t2 + 1.0, -1.5 * t3 + 2.0 * t2 + 0.5 * t, 0.5 * t3 - 0.5 * t2)
+        return torch.stack([b * take((i0 + k).clamp(0, top)) for b, k in zip(basis, (-1, 0, 1, 2))], dim=0).sum(dim=0)
+
+    _, sp, _, _ = linearity_statistics(vals, stds, exposures, lut, mode, ratio_threshold, lo, hi, use_relative, use_unc_weight,
+                                       forward=forward)
+    lin_loss = torch.sqrt((sp ** 2).sum(dim=0))
+    grads = torch.autograd.grad(lin_loss.sum(), taps)
+    out = torch.zeros((c, size), dtype=torch.float64)
+    for g, ix in zip(grads, tap_index):
+        out.index_put_((rows, ix), g.reshape(-1).double(), accumulate=True)
+    return lin_loss.detach(), sp.detach(), out
 
 
 def video_mean_std(frames, lut, mode, batch_sizes):
