@@ -16,11 +16,11 @@ STD_NONE, STD_CONSTANT, STD_MULTIPLIER, STD_EXPLICIT = 0, 1, 2, 3
 WEIGHT_NONE, WEIGHT_GAUSS = 0, 1
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BGR = 0, 1, 2
 MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32, MERGE_F64_MOMENTS = 1, 2, 4, 8
-MERGE_REFERENCE_ORDER, MERGE_CLOSED_FORM, MERGE_STD_HINT = 16, 32, 64
+MERGE_REFERENCE_ORDER, MERGE_CLOSED_FORM, MERGE_STD_HINT, MERGE_REQUIRE_ONE_LAUNCH = 16, 32, 64, 128
 ERR_NO_GRADIENT_PATH = -4
 
 ABI_VERSION = 3
-EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_linearize_std", "ct_linearize_fwd",
+EXPORTS = ("ct_abi_version", "ct_error_string", "ct_hdr_merge_batch", "ct_hdr_merge_batches", "ct_linearize_std", "ct_linearize_fwd",
            "ct_linearize_bwd", "ct_pair_residual_fwd", "ct_pair_residual_bwd", "ct_pair_residual_bwd_workspace", "ct_flatfield_sums",
            "ct_flatfield_apply", "ct_video_stats_batch", "ct_dark_field_blur", "ct_hdr_merge_kernel_name",
            "ct_merge_set_retry_counter", "ct_norm_constants", "ct_index_constants", "ct_pivot_index_constants",

@@ -118,6 +118,10 @@ extern "C" int ct_dark_field_blur(const void *stack_dev, int32_t dtype, float ma
         return CT_ERR_INVALID_ARGUMENT;
     if (geom->layout != CT_LAYOUT_NCHW) return CT_ERR_UNSUPPORTED;
     if (dark_batch != 1 && dark_batch != batch) return CT_ERR_INVALID_ARGUMENT;
+    // One SHARED dark field for several frames with its uncertainty propagated: the reference's autograd on a (1, C, H, W)
+    // mask_map sums the gradient over the frames BEFORE squaring, (sum_n g_n)^2 sigma_D^2, which a per-frame effective
+    // sigma cannot express (it would give sum_n (g_n sigma_D)^2).  Not built; refuse rather than return the other quantity.
+    if (dark_batch == 1 && batch > 1 && dark_std_dev && std_out_dev) return CT_ERR_UNSUPPORTED;
     if (std_mode < CT_STD_NONE || std_mode > CT_STD_EXPLICIT) return CT_ERR_INVALID_ARGUMENT;
     if (std_mode == CT_STD_EXPLICIT && !std_dev) return CT_ERR_INVALID_ARGUMENT;
     if (std_out_dev && !dark_std_dev) return CT_ERR_INVALID_ARGUMENT;

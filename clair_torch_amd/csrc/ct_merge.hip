@@ -531,7 +531,15 @@ struct PivotArgs {
     float tf_max;        // CLAMP: 1.5 * 2^23 + last table entry (codes above max_code clamp to the top of the LUT, base.py:166)
     uint32_t n_entries;  // table entries per LUT row: L (LINEAR), 2 L (LOOKUP)
     unsigned long long *retry_count;  // diagnostics: wavefronts that ran the fallback pass (may be NULL)
+    // MULTI (ct_hdr_merge_batches): several consecutive batches per launch, the streaming state in registers in between
+    int32_t n_batches;                          // 1 .. kMaxMultiBatches
+    int32_t fresh;                              // the first batch starts a merge (no state to read)
+    int32_t batch_size[16];                     // exposures per batch; a.batch = their sum, a.exposure in the same order
+    const void *batch_ptr[16];                  // each batch's (B_b, C, H_tile, W) stack
+    const float *std_ptr[16];                   // CT_STD_EXPLICIT: each batch's std stack
 };
+constexpr int kMaxMultiBatches = 16;
+constexpr int kPivotV = 4;  // elements per thread of merge_pivot_kernel (uint16: 8-byte loads, uint8: 4-byte)
 
 #ifndef CT_PIVOT_DEPTH
 #define CT_PIVOT_DEPTH 2
@@ -559,9 +567,15 @@ constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which
 #ifndef CT_PIVOT_KERNEL_ATTR
 #define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? 7 : 8) : 4, 8)))
 #endif
-template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST, bool CLAMP = false>
+// MULTI: the launch walks x.n_batches consecutive batches per element with (mean, sum of weights, variance) in registers and
+// the per-batch recurrence of WBOMean (statistics.py:64-109, state detached after every batch, hdr_merge.py:128) applied
+// between them -- bit for bit what one launch per batch gives (the first-batch arithmetic with zero state IS the
+// state-carrying arithmetic: W_A = 0 makes frac = 1 and gamma = 0 exactly), without the 32 B per element and batch of
+// state traffic the reference's default batch_size: 4 costs beside 8 B of samples.
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST, bool CLAMP = false, bool MULTI = false>
 __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kernel(const MergeArgs a, const PivotArgs x)
 {
+    static_assert(!MULTI || (!FIRST && CT_PIVOT_TYPED_LOAD), "MULTI carries state and uses the typed loads");
     extern __shared__ __align__(16) char lds[];
     static_assert(sizeof(T) != 4, "raw integer codes only");
     static_assert(INTERP != CT_INTERP_CATMULL, "CATMULL uses merge_kernel / merge_reference_order_kernel");
@@ -714,9 +728,9 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         constexpr int VS = FIRST ? 1 : V;  // state registers exist only when there is state
         float p[V], WA[VS], varA[VS];
         double meanA[VS];
-        if constexpr (FIRST && kTyped) {
+        [[maybe_unused]] auto probe_pivot = [&](uint64_t stack_base) {  // typed loads: p = the probe exposure's y
             const Packet<float, V> pk = load_codes_as_float<T, V>(
-                reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)x.probe * a.image_stride * (int64_t)sizeof(T)), voff);
+                stack_base + (uint64_t)((int64_t)x.probe * a.image_stride * (int64_t)sizeof(T)), voff);
             const float itp = expo[x.probe].x;
             float tf[V];
             if constexpr (kLut) floor_index_bits<V>(pk.v, index_rcp, floor_magic, tf);
@@ -734,6 +748,9 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 }
                 p[e] = lin * itp;
             }
+        };
+        if constexpr (FIRST && kTyped) {
+            probe_pivot(reinterpret_cast<uint64_t>(a.stack));
         } else if constexpr (FIRST) {
             const Packet<T, V> pk = load_buffer<Packet<T, V>>(
                 reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)x.probe * a.image_stride * (int64_t)sizeof(T)), voff);
@@ -750,18 +767,38 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 p[e] = lin * itp;
             });
         } else {
+            bool fresh = false;
+            if constexpr (MULTI) fresh = x.fresh != 0;
+            if (fresh) {  // a new merge: WBOMean starts at mean 0, weight 0 (statistics.py:30-31)
+                if constexpr (MULTI) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const uint32_t q = a.tile.planar_index(q0 + e);
-                meanA[e] = a.mean_state[q];
-                WA[e] = a.sumw_state[q];
-                if constexpr (kHasStd) varA[e] = a.var_state[q];
-                p[e] = (float)meanA[e];
+                    for (int e = 0; e < V; ++e) {
+                        meanA[e] = 0.0;
+                        WA[e] = 0.0f;
+                        varA[e] = 0.0f;
+                    }
+                    probe_pivot(reinterpret_cast<uint64_t>(x.batch_ptr[0]));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const uint32_t q = a.tile.planar_index(q0 + e);
+                    meanA[e] = a.mean_state[q];
+                    WA[e] = a.sumw_state[q];
+                    if constexpr (kHasStd) varA[e] = a.var_state[q];
+                    p[e] = (float)meanA[e];
+                }
             }
         }
 
         double mean_o[V];
         float var_o[V], Wt_o[V];
+        const int n_batches = MULTI ? x.n_batches : 1;
+        int n0 = 0;  // first exposure of the current batch within the launch (a.exposure / the LDS constants)
+        for (int bi = 0; bi < n_batches; ++bi) {
+        const int Bb = MULTI ? x.batch_size[bi] : B;  // exposures of this batch
+        const uint64_t batch_base = MULTI ? reinterpret_cast<uint64_t>(x.batch_ptr[bi]) : reinterpret_cast<uint64_t>(a.stack);
+        [[maybe_unused]] const uint64_t batch_std_base = MULTI ? reinterpret_cast<uint64_t>(x.std_ptr[bi]) : reinterpret_cast<uint64_t>(a.std_stack);
         for (int pass = 0;; ++pass) {
             float W[V], Swy[V], Saa[V], Sac[V], Scc[V];
 #pragma unroll
@@ -891,18 +928,18 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             // (the slot freed by one step is re-filled by the next), so that no packet is ever copied -- a copy would
             // make the wavefront wait for the load it has just issued.
             auto fetch = [&](int n, CodePk &pk, Packet<float, V> &sp) {
-                const int nn = n < B ? n : B - 1;  // past the end: re-load the last exposure (cache hit, unused)
+                const int nn = n < Bb ? n : Bb - 1;  // past the end: re-load the last exposure (cache hit, unused)
                 // Buffer loads: (scalar descriptor rebased to the exposure) + (32-bit per-thread byte offset) -- no vector
                 // address arithmetic.  The base is laundered through an empty asm so LLVM cannot prove the prefetched
                 // packet equal to a fresh load at its use (it would re-load there and drop the prefetch).
-                uint64_t base = reinterpret_cast<uint64_t>(a.stack) + (uint64_t)((int64_t)nn * a.image_stride * (int64_t)sizeof(T));
+                uint64_t base = batch_base + (uint64_t)((int64_t)nn * a.image_stride * (int64_t)sizeof(T));
                 asm volatile("" : "+s"(base));
                 if constexpr (kTyped)
                     pk = load_codes_as_float<T, V>(base, voff);
                 else
                     pk = load_buffer<Packet<T, V>>(base, voff);
                 if constexpr (STD == CT_STD_EXPLICIT) {
-                    uint64_t sbase = reinterpret_cast<uint64_t>(a.std_stack) + (uint64_t)((int64_t)nn * a.image_stride * 4);
+                    uint64_t sbase = batch_std_base + (uint64_t)((int64_t)nn * a.image_stride * 4);
                     asm volatile("" : "+s"(sbase));
                     sp = load_buffer<Packet<float, V>>(sbase, svoff);
                 }
@@ -914,12 +951,12 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 constexpr int j = decltype(jc)::value;
                 fetch(j, ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0]);
             });
-            uint32_t expo_adr = (uint32_t)lut_bytes;  // LDS byte address of this trip's per-exposure constants
-            for (int n = 0; n < B; n += kRing) {
+            uint32_t expo_adr = (uint32_t)lut_bytes + 8u * (uint32_t)n0;  // LDS byte address of this trip's per-exposure constants
+            for (int n = 0; n < Bb; n += kRing) {
                 static_for<kRing>([&](auto jc) {
                     constexpr int j = decltype(jc)::value, slot = (j + kPivotDepth) % kRing;
                     fetch(n + j + kPivotDepth, ring[slot], sring[STD == CT_STD_EXPLICIT ? slot : 0]);
-                    if (j == 0 || n + j < B) reduce(ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0], expo_adr + 8u * j);
+                    if (j == 0 || n + j < Bb) reduce(ring[j], sring[STD == CT_STD_EXPLICIT ? j : 0], expo_adr + 8u * j);
                 });
                 expo_adr += 8u * kRing;
             }
@@ -934,7 +971,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             float mb_f[V];
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const float Wb = kGauss ? W[e] : (float)B;
+                const float Wb = kGauss ? W[e] : (float)Bb;
                 const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
                 float r = __builtin_amdgcn_rcpf(Df);
                 r = r * __builtin_fmaf(-Df, r, 2.0f);
@@ -977,6 +1014,17 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 #pragma unroll
             for (int e = 0; e < V; ++e) p[e] = bad[e] ? mb_f[e] : p[e];
         }
+        if constexpr (MULTI) {  // internal_detach (hdr_merge.py:128): the batch's result is the next batch's state and pivot
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                meanA[e] = mean_o[e];
+                WA[e] = Wt_o[e];
+                varA[e] = var_o[e];
+                p[e] = (float)mean_o[e];
+            }
+            n0 += Bb;
+        }
+        }  // batches
 
         if (keep_state) {
 #pragma unroll
@@ -1094,6 +1142,53 @@ static int dispatch_pivot_interp(const MergeArgs &a, const PivotArgs &x, int int
                  : dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE, false>(a, x, std_mode, s);
 }
 
+// ---- several batches per launch (MULTI): packets of kPivotV only, state-carrying instantiation ----
+template <typename T, int INTERP, int WEIGHT, int STD, bool CLAMP>
+static int launch_pivot_multi(const MergeArgs &a, PivotArgs x, hipStream_t stream)
+{
+    if (a.q_count == 0) return CT_OK;
+    if constexpr (INTERP == CT_INTERP_LOOKUP && WEIGHT == CT_WEIGHT_NONE && STD != CT_STD_NONE) {
+        return CT_ERR_NO_GRADIENT_PATH;
+    } else if constexpr (!CT_PIVOT_TYPED_LOAD) {
+        return CT_ERR_UNSUPPORTED;
+    } else {
+        constexpr int V = kPivotV;
+        x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);
+        constexpr bool kTable = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;
+        constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && sizeof(T) == 2) ? CT_PIVOT_WEIGHT : 0;
+        const size_t lds = (kTable ? (size_t)a.channels * x.n_entries * (kWV == 2 ? 16 : 8) : 0) +
+                           2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
+        if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+        return launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false, CLAMP, true>>(a, x, lds, stream);
+    }
+}
+
+template <typename T, int INTERP, int WEIGHT, bool CLAMP>
+static int dispatch_multi_std(const MergeArgs &a, const PivotArgs &x, int std_mode, hipStream_t s)
+{
+    switch (std_mode) {
+        case CT_STD_NONE: return launch_pivot_multi<T, INTERP, WEIGHT, CT_STD_NONE, CLAMP>(a, x, s);
+        case CT_STD_CONSTANT: return launch_pivot_multi<T, INTERP, WEIGHT, CT_STD_CONSTANT, CLAMP>(a, x, s);
+        case CT_STD_MULTIPLIER: return launch_pivot_multi<T, INTERP, WEIGHT, CT_STD_MULTIPLIER, CLAMP>(a, x, s);
+        case CT_STD_EXPLICIT: return launch_pivot_multi<T, INTERP, WEIGHT, CT_STD_EXPLICIT, CLAMP>(a, x, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
+template <typename T, bool CLAMP>
+static int dispatch_multi_interp(const MergeArgs &a, const PivotArgs &x, int interp, int weight_mode, int std_mode, hipStream_t s)
+{
+    const bool gauss = weight_mode == CT_WEIGHT_GAUSS;
+    if (interp == CT_INTERP_LINEAR)
+        return gauss ? dispatch_multi_std<T, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
+                     : dispatch_multi_std<T, CT_INTERP_LINEAR, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
+    if (interp == CT_INTERP_LOOKUP)
+        return gauss ? dispatch_multi_std<T, CT_INTERP_LOOKUP, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
+                     : dispatch_multi_std<T, CT_INTERP_LOOKUP, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
+    return gauss ? dispatch_multi_std<T, CT_INTERP_NONE, CT_WEIGHT_GAUSS, false>(a, x, std_mode, s)
+                 : dispatch_multi_std<T, CT_INTERP_NONE, CT_WEIGHT_NONE, false>(a, x, std_mode, s);
+}
+
 // CLAMP (codes above max_code exist: max_code below the container's range) costs one v_min per sample, so it is its own
 // instantiation for uint16 packets; the one-element launch of a ragged tail always carries it (its cost is irrelevant);
 // uint8 packets with max_code < 255 are left to the generic kernel (pivot_eligible).
@@ -1176,7 +1271,6 @@ static int dispatch_interp(const MergeArgs &a, int interp, int weight_mode, int 
 // HBM-bound), so 16-byte packets are used.  Rejected on measurement (profiles/r01_harness_*.log): float32 block
 // moments (7 % faster, 1.3e-4 parity error), a two-phase variant caching every sample's (a_n, b_n) in registers to
 // drop the float64 FMAs (exact, but 256 VGPRs and 4-byte loads: 2.4 ms), auto-SLP packed float32 (10 % slower).
-constexpr int kPivotV = 4;  // elements per thread of merge_pivot_kernel (uint16: 8-byte loads, uint8: 4-byte)
 
 template <typename T>
 struct VecWidth {
@@ -1405,4 +1499,107 @@ extern "C" int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float ma
         case CT_DTYPE_F32: return merge_typed<float>(a, (uint32_t)Ql, interp, weight_mode, std_mode, s, false);
     }
     return CT_ERR_UNSUPPORTED;
+}
+
+// Several consecutive batches of one merge in ONE launch (hdr_merge.py:61-128 for k iterations of the loop).
+extern "C" int ct_hdr_merge_batches(const void *const *stack_devs, const float *const *std_devs, const int32_t *batch_sizes,
+                                    int32_t n_batches, int32_t dtype, float max_code, const ct_geometry *geom, int32_t std_mode,
+                                    float std_value, const double *exposure_dev, const ct_icrf *icrf, int32_t weight_mode,
+                                    double *mean_state_dev, float *sumw_state_dev, float *var_state_dev, void *mean_out_dev,
+                                    float *std_out_dev, uint32_t flags, void *stream)
+{
+    using namespace ct;
+    if (!stack_devs || !batch_sizes || n_batches <= 0 || !geom || !icrf || !exposure_dev) return CT_ERR_INVALID_ARGUMENT;
+    if (std_mode == CT_STD_EXPLICIT && !std_devs) return CT_ERR_INVALID_ARGUMENT;
+    int64_t total = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        if (!stack_devs[b] || batch_sizes[b] <= 0 || (std_mode == CT_STD_EXPLICIT && !std_devs[b])) return CT_ERR_INVALID_ARGUMENT;
+        total += batch_sizes[b];
+    }
+    const bool first = flags & CT_MERGE_FIRST_BATCH, finalize = flags & CT_MERGE_FINALIZE;
+    const bool has_state = mean_state_dev && sumw_state_dev && (std_mode == CT_STD_NONE || var_state_dev);
+    const int interp = icrf->interp;
+    // the one-launch path: what ct::merge_pivot_kernel addresses in the code domain, whole packets everywhere
+    bool fast = n_batches >= 2 && n_batches <= kMaxMultiBatches && total <= 0x7fffffff && (has_state || (first && finalize)) &&
+                (dtype == CT_DTYPE_U8 || dtype == CT_DTYPE_U16) && geom->channels > 0 && geom->h_tile > 0 && geom->width > 0 &&
+                interp >= CT_INTERP_LOOKUP && interp <= CT_INTERP_NONE && !(flags & CT_MERGE_F64_MOMENTS) &&
+                !merge_uses_reference_order(interp, std_mode, flags) &&
+                !(std_mode != CT_STD_NONE && interp == CT_INTERP_LOOKUP && weight_mode == CT_WEIGHT_NONE);
+    PivotArgs px{};
+    bool clamp = false;
+    const int64_t Ql = geom->h_tile * geom->width * geom->channels;
+    const size_t tsize = dtype == CT_DTYPE_U8 ? 1 : 2;
+    if (fast) fast = pivot_eligible(dtype, max_code, interp, interp == CT_INTERP_NONE ? 2 : icrf->n_points, flags, &px, &clamp);
+    if (fast) {
+        auto aligned = [](const void *p, size_t bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+        fast = Ql % kPivotV == 0 && geom->image_stride % kPivotV == 0 && aligned(mean_out_dev, 8 * kPivotV) &&
+               aligned(std_out_dev, 4 * kPivotV);
+        for (int b = 0; fast && b < n_batches; ++b)
+            fast = aligned(stack_devs[b], tsize * kPivotV) && (std_mode != CT_STD_EXPLICIT || aligned(std_devs[b], 4 * kPivotV));
+    }
+    if (!fast && (flags & CT_MERGE_REQUIRE_ONE_LAUNCH)) return CT_ERR_UNSUPPORTED;  // (tests: make the route explicit)
+    if (!fast) {
+        // one launch per batch with the state in memory (exactly what the caller would have done)
+        if (n_batches > 1 && !has_state) return CT_ERR_INVALID_ARGUMENT;
+        int64_t n0 = 0;
+        for (int b = 0; b < n_batches; ++b) {
+            const uint32_t f = (flags & ~(CT_MERGE_FIRST_BATCH | CT_MERGE_FINALIZE)) | ((first && b == 0) ? CT_MERGE_FIRST_BATCH : 0u) |
+                               ((finalize && b == n_batches - 1) ? CT_MERGE_FINALIZE : 0u);
+            const int rc = ct_hdr_merge_batch(stack_devs[b], dtype, max_code, batch_sizes[b], geom, std_devs ? std_devs[b] : nullptr,
+                                              std_mode, std_value, exposure_dev + n0, icrf, weight_mode, mean_state_dev,
+                                              sumw_state_dev, var_state_dev, mean_out_dev, std_out_dev, f, stream);
+            if (rc != CT_OK) return rc;
+            n0 += batch_sizes[b];
+        }
+        return CT_OK;
+    }
+    // argument checks of ct_hdr_merge_batch that the fast path still owes
+    if (geom->h_global < geom->h_tile || geom->row_offset < 0 || geom->row_offset + geom->h_tile > geom->h_global) return CT_ERR_INVALID_ARGUMENT;
+    if (geom->layout < CT_LAYOUT_NCHW || geom->layout > CT_LAYOUT_NHWC_BGR) return CT_ERR_INVALID_ARGUMENT;
+    if (interp != CT_INTERP_NONE && (!icrf->lut_dev || icrf->n_points < 2)) return CT_ERR_INVALID_ARGUMENT;
+    if (std_mode < CT_STD_NONE || std_mode > CT_STD_EXPLICIT) return CT_ERR_INVALID_ARGUMENT;
+    if (weight_mode != CT_WEIGHT_NONE && weight_mode != CT_WEIGHT_GAUSS) return CT_ERR_INVALID_ARGUMENT;
+    if (finalize && (!mean_out_dev || (std_mode != CT_STD_NONE && !std_out_dev))) return CT_ERR_INVALID_ARGUMENT;
+    const int64_t plane_g = geom->h_global * geom->width, plane_l = geom->h_tile * geom->width;
+    if (plane_g * geom->channels >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
+    if (geom->image_stride < Ql) return CT_ERR_INVALID_ARGUMENT;
+    MergeArgs a{};
+    a.stack = stack_devs[0];
+    a.std_stack = std_mode == CT_STD_EXPLICIT ? std_devs[0] : nullptr;
+    a.exposure = exposure_dev;
+    a.lut = icrf->lut_dev;
+    a.mean_state = has_state ? mean_state_dev : nullptr;
+    a.sumw_state = has_state ? sumw_state_dev : nullptr;
+    a.var_state = has_state ? var_state_dev : nullptr;
+    a.mean_out = mean_out_dev;
+    a.std_out = std_out_dev;
+    a.image_stride = geom->image_stride;
+    a.q_begin = 0;
+    a.q_count = (uint32_t)Ql;
+    a.tile.plane_local = (uint32_t)plane_l;
+    a.tile.chan_skip = (uint32_t)(plane_g - plane_l);
+    a.tile.base = (uint32_t)(geom->row_offset * geom->width);
+    a.tile.layout = (uint32_t)geom->layout;
+    a.tile.channels = (uint32_t)geom->channels;
+    a.batch = (int32_t)total;
+    a.channels = geom->channels;
+    a.n_points = interp == CT_INTERP_NONE ? 2 : icrf->n_points;
+    a.std_value = std_value;
+    a.weight_scale = 30.0f;
+    a.inv_max_code = (float)(1.0 / (double)max_code);
+    a.flags = flags;
+    if (ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+    px.n_batches = n_batches;
+    px.fresh = first ? 1 : 0;
+    px.probe = batch_sizes[0] / 2;
+    px.retry_count = g_merge_retry_counter;
+    for (int b = 0; b < n_batches; ++b) {
+        px.batch_size[b] = batch_sizes[b];
+        px.batch_ptr[b] = stack_devs[b];
+        px.std_ptr[b] = std_mode == CT_STD_EXPLICIT ? std_devs[b] : nullptr;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == CT_DTYPE_U8) return dispatch_multi_interp<uint8_t, false>(a, px, interp, weight_mode, std_mode, s);
+    return clamp ? dispatch_multi_interp<uint16_t, true>(a, px, interp, weight_mode, std_mode, s)
+                 : dispatch_multi_interp<uint16_t, false>(a, px, interp, weight_mode, std_mode, s);
 }

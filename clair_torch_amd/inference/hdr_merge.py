@@ -50,6 +50,27 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
     pending = next(batches, None)
     if pending is None:
         raise ValueError("dataloader yielded no batches")
+    # Consecutive batches are queued (staged on the device, not yet merged) and handed over together: one
+    # ct_hdr_merge_batches call keeps the streaming state in registers across up to 16 batches instead of writing and
+    # re-reading 32 B per element after every one of them (the reference's default is batch_size: 4).  The result is the
+    # same bit for bit as merging batch by batch (per-batch detach of the state, hdr_merge.py:128, included).
+    queue, queue_key = [], None
+
+    def flush(final):
+        nonlocal state, result, queue
+        if not queue:
+            return
+        k0 = queue[0]
+        if state is None and (not final or flat_field_dataset is not None):
+            chw = tuple(k0["images"].shape[1:]) if k0["layout"] == "nchw" else (k0["images"].shape[3], k0["images"].shape[1], k0["images"].shape[2])
+            state = ops.MergeState(chw, dev, with_variance=k0["std_mode"] != "none")
+        stds = None if k0["std"] is None else [q["std"] for q in queue]
+        result = ops.hdr_merge_batches([q["images"] for q in queue], [q["exposure"] for q in queue], lut=lut, interp=interp,
+                                       gaussian_weight=weight_fn is not None, stds=stds, std_mode=k0["std_mode"],
+                                       std_value=k0["std_value"], max_code=k0["max_code"], state=state,
+                                       finalize=final and flat_field_dataset is None, tile=tile, layout=k0["layout"])
+        queue = []
+
     while pending is not None:
         index_batch, val_batch, std_batch, meta_batch = pending
         pending = next(batches, None)
@@ -62,13 +83,14 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
             xb, sig = dark.apply(index_batch, images, max_code, std, std_mode, std_value, tile, group)
             if xb is not None:  # the blurred batch replaces the images; its uncertainty carries both variance terms
                 images, max_code, std, std_mode, std_value = xb, None, sig, "explicit", 0.0
-        if state is None and (not last or flat_field_dataset is not None):
-            chw = tuple(images.shape[1:]) if layout == "nchw" else (images.shape[3], images.shape[1], images.shape[2])
-            state = ops.MergeState(chw, dev, with_variance=std_mode != "none")
-        result = ops.hdr_merge_batch(images, meta_batch["exposure_time"], lut=lut, interp=interp,
-                                     gaussian_weight=weight_fn is not None, std=std, std_mode=std_mode,
-                                     std_value=std_value, max_code=max_code, state=state,
-                                     finalize=last and flat_field_dataset is None, tile=tile, layout=layout)
+        key = (images.dtype, tuple(images.shape[1:]), max_code, layout, std_mode, std_value, std is None)
+        if queue and (key != queue_key or len(queue) == ops.MAX_MERGE_BATCHES):
+            flush(False)
+        queue_key = key
+        queue.append(dict(images=images, exposure=meta_batch["exposure_time"], std=std, std_mode=std_mode, std_value=std_value,
+                          max_code=max_code, layout=layout))
+        if last:
+            flush(True)
     if flat_field_dataset is not None:
         return _flat_field_epilogue(state, flat_field_dataset, dataloader.dataset, dev, tile, group)
     mean, std = result

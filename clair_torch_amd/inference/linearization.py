@@ -105,6 +105,11 @@ class _Slot:
 
 
 def _pipelined(first, items, dataloader, dev, lut, interp, flat, flat_std, max_code, layout):
+    # Memory note for consumers: the yielded CPU tensors of one group (up to _GROUP_BYTES = 256 MB of output, 5 frames of
+    # 1080p RGB) are views of two pinned host tensors, so keeping ONE frame alive keeps its group's pinned pages, and
+    # list(generator) page-locks the whole output.  The reference hands out independent pageable .cpu() copies; copying
+    # here would cost a 50 MB host memcpy per frame (a fifth of the pipeline's throughput), so a consumer that collects
+    # frames should .clone() what it keeps.
     probe = first[1]
     frame_shape = tuple(probe.shape[1:])
     chw = frame_shape if layout == "nchw" else (frame_shape[2], frame_shape[0], frame_shape[1])
@@ -139,9 +144,11 @@ def _pipelined(first, items, dataloader, dev, lut, interp, flat, flat_std, max_c
                 if tuple(val_batch.shape[1:]) != frame_shape or val_batch.dtype != probe.dtype:
                     raise ValueError("all frames of one linearization run must share shape and dtype")
                 slot.frames[k].copy_(val_batch[0], non_blocking=True)
+                if with_std != (std_batch is not None):
+                    # the pipeline's buffers and kernel variant follow the FIRST frame; a stream that mixes frames with
+                    # and without an uncertainty image is refused rather than silently ignoring some of them
+                    raise ValueError("uncertainty images present for some frames only")
                 if with_std:
-                    if std_batch is None:
-                        raise ValueError("uncertainty images present for some frames only")
                     slot.std[k].copy_(std_batch[0], non_blocking=True)
                 metas.append(meta_batch)
                 k += 1

@@ -172,6 +172,92 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
     return (mean_out, std_out) if finalize else None
 
 
+MAX_MERGE_BATCHES = 16  # batches one ct_hdr_merge_batches call takes (the kernel's argument block holds 16 pointers)
+
+
+def hdr_merge_batches(stacks, exposures, *, lut: Optional[torch.Tensor] = None, interp: Optional[str] = "linear",
+                      gaussian_weight: bool = True, stds=None, std_mode: str = "none", std_value: float = 0.0,
+                      max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
+                      tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw",
+                      reference_order: Optional[bool] = None, require_one_launch: bool = False):
+    """Several CONSECUTIVE batches of one merge in one call (ct_hdr_merge_batches): the same result, bit for bit, as
+    hdr_merge_batch on each of them in turn with ``state`` carried along -- but where the pivoted code-domain kernel
+    applies the streaming state stays in registers between the batches (one launch, no state traffic).
+
+    ``stacks``: list of (B_k,C,H,W) device tensors of one dtype / geometry (each sorted by exposure like custom_collate);
+    ``exposures``: list of (B_k) tensors; ``stds``: list of explicit std tensors or None.  At most MAX_MERGE_BATCHES.
+    ``require_one_launch`` (tests): raise instead of falling back to one launch per batch.
+    Returns (mean, std|None) when ``finalize`` else None."""
+    k = len(stacks)
+    if k == 0 or k != len(exposures) or (stds is not None and len(stds) != k):
+        raise ValueError("stacks / exposures / stds must be non-empty lists of equal length")
+    if k > MAX_MERGE_BATCHES:
+        raise ValueError(f"at most {MAX_MERGE_BATCHES} batches per call")
+    if k == 1:
+        return hdr_merge_batch(stacks[0], exposures[0], lut=lut, interp=interp, gaussian_weight=gaussian_weight,
+                               std=None if stds is None else stds[0], std_mode=std_mode, std_value=std_value, max_code=max_code,
+                               state=state, finalize=finalize, tile=tile, mean_dtype=mean_dtype, layout=layout,
+                               reference_order=reference_order)
+    for t in stacks:
+        _check_stack(t)
+        if t.dtype != stacks[0].dtype or t.shape[1:] != stacks[0].shape[1:] or t.device != stacks[0].device:
+            raise ValueError("all batches of one call must share dtype, image shape and device")
+    dev = stacks[0].device
+    c, h, w = _chw(stacks[0], layout)
+    if stds is not None:
+        std_mode = "explicit"
+        stds = [sd.to(device=dev, dtype=torch.float32).contiguous() for sd in stds]
+        for sd, t in zip(stds, stacks):
+            if sd.shape != t.shape:
+                raise ValueError(f"std shape {tuple(sd.shape)} != stack shape {tuple(t.shape)}")
+    if std_mode not in _STD:
+        raise ValueError(f"unknown std_mode {std_mode}")
+    stacks = [t.contiguous() for t in stacks]
+    if stacks[0].dtype != torch.float32 and max_code is None:
+        max_code = 255.0 if stacks[0].dtype == torch.uint8 else 65535.0
+    sizes = [int(t.shape[0]) for t in stacks]
+    for e, n in zip(exposures, sizes):
+        if e.numel() != n:
+            raise ValueError(f"{e.numel()} exposure times for a batch of {n}")
+    host_exp = torch.cat([e.detach().to("cpu", torch.float64).reshape(-1) for e in exposures])
+    exposure_dev = host_exp.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else host_exp
+    icrf, lut_keep = _icrf_struct(lut, interp, c)
+    geom = _geometry(stacks[0], tile, layout)
+    has_std = std_mode != "none"
+    first = state is None or state.batches == 0
+    flags = (nv.MERGE_FIRST_BATCH if first else 0) | (nv.MERGE_FINALIZE if finalize else 0)
+    if reference_order is not None:
+        flags |= nv.MERGE_REFERENCE_ORDER if reference_order else nv.MERGE_CLOSED_FORM
+    if require_one_launch:
+        flags |= nv.MERGE_REQUIRE_ONE_LAUNCH
+    if mean_dtype == torch.float32:
+        flags |= nv.MERGE_MEAN_OUT_F32
+    elif mean_dtype != torch.float64:
+        raise TypeError("mean_dtype must be float64 (reference) or float32")
+    if state is None and not finalize:
+        raise ValueError("a non-final call needs a MergeState")
+    if state is None:
+        # several batches: whatever cannot run as one launch walks them with the state in memory
+        state = MergeState((c, h, w), dev, has_std)
+    if has_std and state.var is None:
+        raise ValueError("MergeState was created without a variance buffer")
+    mean_out = torch.empty((c, h, w), dtype=mean_dtype, device=dev) if finalize else None
+    std_out = torch.empty((c, h, w), dtype=torch.float32, device=dev) if (finalize and has_std) else None
+    ptr_arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in stacks])
+    std_arr = (ctypes.c_void_p * k)(*[sd.data_ptr() for sd in stds]) if stds is not None else None
+    size_arr = (ctypes.c_int32 * k)(*sizes)
+    with torch.cuda.device(dev):
+        rc = nv.load().ct_hdr_merge_batches(
+            ptr_arr, std_arr, size_arr, k, _DTYPE[stacks[0].dtype], float(max_code or 1.0), ctypes.byref(geom), _STD[std_mode],
+            float(std_value), _ptr(exposure_dev), ctypes.byref(icrf), nv.WEIGHT_GAUSS if gaussian_weight else nv.WEIGHT_NONE,
+            _ptr(state.mean), _ptr(state.sumw), _ptr(state.var) if state.var is not None else None, _ptr(mean_out),
+            _ptr(std_out), flags, _stream(dev))
+    nv.check(rc, "ct_hdr_merge_batches")
+    del lut_keep
+    state.batches += k
+    return (mean_out, std_out) if finalize else None
+
+
 def linearize_frames(frames: torch.Tensor, lut: torch.Tensor, interp: str = "linear", *,
                      std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                      max_code: Optional[float] = None, want_std: bool = True, tile: Optional[TileGeometry] = None,
@@ -481,6 +567,11 @@ def dark_field_blur(stack: torch.Tensor, dark: torch.Tensor, dark_std: Optional[
         dark_std = dark_std.to(device=dev, dtype=torch.float32).contiguous()
         if dark_std.shape != dark.shape:
             raise ValueError("dark_std shape != dark shape")
+        if dark.shape[0] == 1 and b > 1:
+            raise NotImplementedError(
+                "one shared dark field for several frames with its uncertainty: the reference sums the dark-field gradient "
+                "over the frames before squaring, which the per-frame effective sigma of this kernel cannot express; pass "
+                "one (matched) dark field per frame, as get_matching_artefact_images does")
     if halo is not None:
         halo = halo.to(device=dev, dtype=stack.dtype).contiguous()
         if tuple(halo.shape) != (b, c, 2, w):

@@ -68,6 +68,7 @@ extern "C" {
                                         float64 exp / divisions; ct_merge_exact.hip).  Default for LOOKUP and CATMULL with
                                         uncertainties, whose reference results are dominated by float32 cancellation */
 #define CT_MERGE_CLOSED_FORM 32u     /* keep the fast closed-form kernels for LOOKUP / CATMULL with uncertainties as well */
+#define CT_MERGE_REQUIRE_ONE_LAUNCH 128u /* ct_hdr_merge_batches: CT_ERR_UNSUPPORTED instead of one launch per batch */
 #define CT_MERGE_STD_HINT 64u        /* ct_hdr_merge_kernel_name only: uncertainties are propagated */
 
 /* Memory layout of one image of a stack.  Outputs and state are always planar (C, H, W) like the reference's tensors.
@@ -121,6 +122,24 @@ int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int
                        const float *std_dev, int32_t std_mode, float std_value, const double *exposure_dev,
                        const ct_icrf *icrf, int32_t weight_mode, double *mean_state_dev, float *sumw_state_dev,
                        float *var_state_dev, void *mean_out_dev, float *std_out_dev, uint32_t flags, void *stream);
+
+/*
+ * ct_hdr_merge_batches -- n_batches consecutive iterations of compute_hdr_image's loop (hdr_merge.py:61-128) in one call:
+ * exactly ct_hdr_merge_batch applied to batch 0 .. n_batches-1 in turn (CT_MERGE_FIRST_BATCH on batch 0 and
+ * CT_MERGE_FINALIZE on the last one when set in `flags`), bit for bit.  Where the pivoted code-domain kernel applies and
+ * every batch is packet-aligned (n_batches <= 16) it is ONE launch that keeps (mean, sum of weights, variance) in
+ * registers between the batches -- the reference's default batch_size: 4 (scripts/config.yaml) otherwise moves 32 B of
+ * state per element and batch beside 8 B of samples; anything else runs one launch per batch.
+ *   stack_devs / std_devs / batch_sizes  HOST arrays of n_batches device pointers / sizes (std_devs NULL unless EXPLICIT);
+ *                                        every batch is (B_b, C, H_tile, W) with the common geometry, sorted as collate does
+ *   exposure_dev                         the exposure times of all batches, concatenated in the same order (device)
+ *   state / outputs / flags              as ct_hdr_merge_batch; the state may be NULL when flags has FIRST_BATCH and FINALIZE
+ */
+int ct_hdr_merge_batches(const void *const *stack_devs, const float *const *std_devs, const int32_t *batch_sizes,
+                         int32_t n_batches, int32_t dtype, float max_code, const ct_geometry *geom, int32_t std_mode,
+                         float std_value, const double *exposure_dev, const ct_icrf *icrf, int32_t weight_mode,
+                         double *mean_state_dev, float *sumw_state_dev, float *var_state_dev, void *mean_out_dev,
+                         float *std_out_dev, uint32_t flags, void *stream);
 
 /*
  * Host-side proofs behind the folded integer paths (no device work; results cached per argument set):

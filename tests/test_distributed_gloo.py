@@ -174,6 +174,23 @@ class _OracleBackedLibrary:
                 self._arr(std_out, (c, h, w), np.float32)[...] = np.sqrt(st.var)
         return 0
 
+    def ct_hdr_merge_batches(self, stacks, stds, sizes, k, dtype, max_code, geom, std_mode, std_value, exposure, icrf,
+                             weight_mode, mean_state, sumw_state, var_state, mean_out, std_out, flags, stream):
+        # the entry point's contract: ct_hdr_merge_batch on every batch in turn (FIRST on the first, FINALIZE on the last)
+        from clair_torch_amd import _native as nv
+        n0 = 0
+        for b in range(k):
+            f = flags & ~(nv.MERGE_FIRST_BATCH | nv.MERGE_FINALIZE)
+            f |= nv.MERGE_FIRST_BATCH if (flags & nv.MERGE_FIRST_BATCH and b == 0) else 0
+            f |= nv.MERGE_FINALIZE if (flags & nv.MERGE_FINALIZE and b == k - 1) else 0
+            rc = self.ct_hdr_merge_batch(stacks[b], dtype, max_code, sizes[b], geom, stds[b] if stds else None, std_mode, std_value,
+                                         self.ct.c_void_p(exposure.value + 8 * n0), icrf, weight_mode, mean_state, sumw_state,
+                                         var_state, mean_out, std_out, f, stream)
+            if rc != 0:
+                return rc
+            n0 += sizes[b]
+        return 0
+
     def ct_flatfield_sums(self, value, is_f64, flat, c, plane, sums, stream):
         f = self._arr(flat, (c, plane), np.float32)
         s = self._arr(sums, (c, 2), np.float64)

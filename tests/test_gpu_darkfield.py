@@ -41,7 +41,14 @@ def test_blur_kernel_against_restated_torchvision(dev):
     from oracle import eager_torch as oe
     x, sd, _, dark, dark_std, _ = _scene(3, 4, 3, 13, 9)
     ref = oe.conditional_gaussian_blur(x, dark.unsqueeze(0))
-    xb, sig = ops.dark_field_blur(x.to(dev), dark.unsqueeze(0).to(dev), dark_std.unsqueeze(0).to(dev), std=sd.to(dev))
+    nb = x.shape[0]   # one matched dark field per frame (get_matching_artefact_images collates B copies)
+    xb, sig = ops.dark_field_blur(x.to(dev), dark.expand(nb, *dark.shape).to(dev), dark_std.expand(nb, *dark.shape).to(dev), std=sd.to(dev))
+    # ONE shared dark field for several frames with its uncertainty is a different quantity in the reference
+    # ((sum_n g_n)^2 sigma_D^2): refused, not approximated
+    with pytest.raises(NotImplementedError, match="shared dark field"):
+        ops.dark_field_blur(x.to(dev), dark.unsqueeze(0).to(dev), dark_std.unsqueeze(0).to(dev), std=sd.to(dev))
+    xb_shared, none_sig = ops.dark_field_blur(x.to(dev), dark.unsqueeze(0).to(dev), None, std=None)   # without a dark std: fine
+    assert none_sig is None and torch.equal(xb_shared, xb)
     assert_parity(xb.cpu().numpy(), ref.numpy(), rtol=1e-6, norm_tol=1e-7, what="blurred batch")
     m = torch.sigmoid((dark - 0.05) * 50.0)
     dterm = (oe.gaussian_blur3(x) - x) * (50.0 * m * (1 - m))
@@ -53,8 +60,8 @@ def test_blur_kernel_against_restated_torchvision(dev):
     assert_parity(xb2.cpu().numpy(), ref2.numpy(), rtol=1e-6, norm_tol=1e-7, what="per-frame dark fields")
     codes = torch.round(x * 65535).to(torch.int32).numpy().astype(np.uint16)
     xc = torch.from_numpy(oc.normalize_codes(codes))
-    xb3, sig3 = ops.dark_field_blur(torch.from_numpy(codes).to(dev), dark.unsqueeze(0).to(dev), dark_std.unsqueeze(0).to(dev),
-                                    std_mode="multiplier", std_value=0.05)
+    xb3, sig3 = ops.dark_field_blur(torch.from_numpy(codes).to(dev), dark.expand(nb, *dark.shape).to(dev),
+                                    dark_std.expand(nb, *dark.shape).to(dev), std_mode="multiplier", std_value=0.05)
     assert_parity(xb3.cpu().numpy(), oe.conditional_gaussian_blur(xc, dark.unsqueeze(0)).numpy(), rtol=1e-6, norm_tol=1e-7,
                   what="blurred batch from codes")
     dterm3 = (oe.gaussian_blur3(xc) - xc) * (50.0 * m * (1 - m))
@@ -66,7 +73,9 @@ def test_bands_with_halo_equal_whole(dev):
     """Row bands with the neighbouring rows as halo reproduce the untiled blur bit for bit."""
     from clair_torch_amd import ops
     x, sd, _, dark, dark_std, _ = _scene(4, 3, 3, 17, 8)
-    xd, sdd, dd, dsd = x.to(dev), sd.to(dev), dark.unsqueeze(0).to(dev), dark_std.unsqueeze(0).to(dev)
+    nb = x.shape[0]
+    xd, sdd = x.to(dev), sd.to(dev)
+    dd, dsd = dark.expand(nb, *dark.shape).contiguous().to(dev), dark_std.expand(nb, *dark.shape).contiguous().to(dev)
     xb, sig = ops.dark_field_blur(xd, dd, dsd, std=sdd)
     h = x.shape[2]
     for r0, r1 in ((0, 6), (6, 11), (11, 17)):

@@ -246,6 +246,20 @@ def _train_inputs(g, sname):
     return x, sd
 
 
+@pytest.mark.parametrize("mode", ["linear", "catmull"])
+@pytest.mark.parametrize("relative", [True, False])
+def test_float64_scatter_lut_gradient_agrees_with_the_recorded_one(mode, relative):
+    """oracle/eager_torch.linearity_lut_grad_f64 (explicit LUT taps, per-sample gradients from autograd, scatter in
+    float64 -- the comparand of the backward kernels) against the reference's recorded LUT gradient of the linearity term
+    (float32 index_put): same chain, the only difference is the accumulation -- 1e-6 norm-wise."""
+    g = golden("training")
+    x, _ = _train_inputs(g, "none")
+    ref = g[f"train_none_{mode}_{'rel' if relative else 'abs'}_nounc_lingrad"]
+    _, _, grad = oe.linearity_lut_grad_f64(torch.from_numpy(x), None, torch.from_numpy(g["train_exposures"]),
+                                           torch.from_numpy(g["train_lut0"]), mode, 0.25, 1 / 255, 254 / 255, relative, False)
+    assert_parity(grad.numpy(), ref, rtol=1e-5, norm_tol=1e-6, what="float64-scatter LUT gradient")
+
+
 def test_exposure_pairs_known_answers():
     g = golden("helpers")
     i, j, r = oc.exposure_pairs([1.0, 2.0, 4.0], 0.4)           # reference test_general_functions.py:290-327
