@@ -72,6 +72,10 @@ def load():
     lib.ct_error_string.argtypes = [i32]
     lib.ct_hdr_merge_batch.restype = i32
     lib.ct_hdr_merge_batch.argtypes = [vp, i32, f32, i32, gp, vp, i32, f32, vp, ip, i32, vp, vp, vp, vp, vp, u32, vp]
+    lib.ct_hdr_merge_batches.restype = i32
+    lib.ct_hdr_merge_batches.argtypes = [vp, vp, vp, i32, i32, f32, gp, i32, f32, vp, ip, i32, vp, vp, vp, vp, vp, u32, vp]
+    lib.ct_pivot_interval_constants.restype = i32
+    lib.ct_pivot_interval_constants.argtypes = [f32, i32, i32, i32, ctypes.POINTER(f32)]
     lib.ct_linearize_std.restype = i32
     lib.ct_linearize_std.argtypes = [vp, i32, f32, i64, gp, vp, i32, f32, ip, vp, vp, vp]
     lib.ct_linearize_fwd.restype = i32

@@ -350,6 +350,15 @@ struct TileMap {
         channel = (int)(ql / plane_local);
         q_global = ql + (uint32_t)channel * chan_skip + base;
     }
+    // Interleaved RGB / BGR (C == 3, the layout OpenCV decodes to) with constant divisors: memory element m -> channel
+    // plane c, pixel, and the planar index; a runtime 32-bit division costs ~30 instructions each, three of them per
+    // element made the interleaved merge 9 % slower than the planar one (profiles/r03_layout_ingest.md).
+    __device__ __forceinline__ void interleaved3(uint32_t m, uint32_t &c, uint32_t &pixel) const
+    {
+        pixel = m / 3u;
+        const uint32_t cm = m - 3u * pixel;
+        c = layout == CT_LAYOUT_NHWC_BGR ? 2u - cm : cm;
+    }
     // Memory element m of one image -> planar (C, H_tile, W) index.  For NCHW this is the identity; for the
     // interleaved layouts element m is channel m % C of pixel m / C (channel order reversed for BGR).
     __device__ __forceinline__ uint32_t planar_index(uint32_t m) const

@@ -132,6 +132,133 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
     }
 }
 
+// Interleaved RGB / BGR frames (C == 3: what OpenCV decodes to, clair_torch/common/data_io.py:125-154): a thread owns four
+// consecutive PIXELS = 12 memory elements (three typed loads of four codes each, or three 16-byte loads of float pixels),
+// so every channel plane of the planar outputs receives its four consecutive pixels as ONE 16-byte streaming store.  The
+// element-per-thread mapping of linearize_kernel scatters 4-byte stores over three planes and pays three runtime divisions
+// per element: 2.09 ms against 0.85 ms for the planar layout on C4 (profiles/r03_layout_ingest.md).  Per-element arithmetic
+// is the same function call, so results are bit-identical to the planar path.  q_begin / q_count are multiples of 12.
+template <typename T, int INTERP, int STD, bool WRITE_STD>
+__global__ __launch_bounds__(kBlock) void linearize_rgb_kernel(const LinArgs a)
+{
+    extern __shared__ __align__(16) char lds[];
+    constexpr bool kRanged = sizeof(T) != 4;
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    const int L = a.n_points;
+    stage_lut<INTERP>(lds, a.lut, 3, L);
+    __syncthreads();
+    const uint32_t pv = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    if (pv * 12u >= a.q_count) return;
+    const uint32_t m0 = a.q_begin + pv * 12u;  // first memory element of this thread (within one frame)
+    const uint32_t pix0 = m0 / 3u;             // local pixel index (m0 is a multiple of 12)
+    const float top = (float)(L - 1);
+    const bool bgr = a.tile.layout == CT_LAYOUT_NHWC_BGR;
+    // LUT row of element (channel plane c, pixel pix0 + j): (c * plane_global + base + pix0 + j) % 3 (base.py:173-176)
+    const uint32_t pg = (a.tile.plane_local + a.tile.chan_skip) % 3u, mrow = (a.tile.base + pix0) % 3u;
+    int row_off[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const uint32_t j = k / 3, cm = k % 3, c = bgr ? 2u - cm : cm;
+        row_off[k] = (int)(INTERP == CT_INTERP_LOOKUP ? c : (c * pg + mrow + j) % 3u) * L * kEntry;
+    }
+    for (uint32_t f = blockIdx.y; f < a.n_frames; f += gridDim.y) {
+        float xin[12];
+        if constexpr (sizeof(T) != 4) {
+            const uint64_t base = reinterpret_cast<uint64_t>(a.frames) + (uint64_t)((int64_t)f * a.image_stride * (int64_t)sizeof(T));
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                float part[4];
+                load_codes_as_float<T, 4>(base, (m0 + 4u * h) * (uint32_t)sizeof(T), part);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xin[4 * h + k] = part[k];
+            }
+        } else {
+            const T *src = static_cast<const T *>(a.frames) + (int64_t)f * a.image_stride + m0;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                const LPacket<T, 4> pk = *reinterpret_cast<const LPacket<T, 4> *>(src + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xin[4 * h + k] = pk.v[k];
+            }
+        }
+        float lin[12], sd[12];
+        [[maybe_unused]] bool tiny = false;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float x = sizeof(T) != 4 ? code_to_pixel(xin[k], a.norm) : xin[k];
+            float dfdx;
+            lin[k] = icrf_sample<INTERP, true, kRanged>(x, lds + row_off[k], top, dfdx);
+            sd[k] = 0.0f;
+            if constexpr (WRITE_STD && STD != CT_STD_NONE) {
+                float sigma = a.std_value;                                          // CONSTANT
+                if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;    // datasets/base.py:133
+                const float ags = fabsf(dfdx * sigma);  // sqrt((grad * std)^2) = |grad * std| unless the square underflows
+                sd[k] = ags;
+                tiny |= ags < 1e-18f && ags != 0.0f;
+            }
+        }
+        if constexpr (WRITE_STD && STD != CT_STD_NONE) {
+            if (__builtin_expect(__any(tiny), 0)) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k)
+                    if (sd[k] < 1e-18f && sd[k] != 0.0f) sd[k] = sqrtf(sd[k] * sd[k]);
+            }
+        }
+        const int64_t obase = (int64_t)f * a.out_stride + pix0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cm = bgr ? 2 - c : c;
+            LPacket<float, 4> lo, so;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo.v[j] = lin[3 * j + cm];
+                so.v[j] = sd[3 * j + cm];
+            }
+            store_stream(reinterpret_cast<LPacket<float, 4> *>(a.lin_out + obase + (int64_t)c * a.tile.plane_local), lo);
+            if constexpr (WRITE_STD)
+                store_stream(reinterpret_cast<LPacket<float, 4> *>(a.std_out + obase + (int64_t)c * a.tile.plane_local), so);
+        }
+    }
+}
+
+template <typename T, int INTERP, int STD, bool WRITE_STD>
+static int lin_launch_rgb(const LinArgs &a, hipStream_t s)
+{
+    if (a.q_count == 0 || a.n_frames == 0) return CT_OK;
+    const uint32_t vecs = a.q_count / 12, gx = (vecs + kBlock - 1) / kBlock;
+    uint32_t gy = (a.n_frames + 1) / 2;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    const size_t lds = INTERP == CT_INTERP_NONE ? 0 : (size_t)3 * a.n_points * lut_entry_bytes(INTERP);
+    if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+    hipLaunchKernelGGL((linearize_rgb_kernel<T, INTERP, STD, WRITE_STD>), dim3(gx, gy), dim3(kBlock), lds, s, a);
+    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int INTERP>
+static int lin_dispatch_rgb_std(const LinArgs &a, int std_mode, bool write_std, hipStream_t s)
+{
+    if (!write_std) return lin_launch_rgb<T, INTERP, CT_STD_NONE, false>(a, s);
+    switch (std_mode) {
+        case CT_STD_NONE: return lin_launch_rgb<T, INTERP, CT_STD_NONE, true>(a, s);
+        case CT_STD_CONSTANT: return lin_launch_rgb<T, INTERP, CT_STD_CONSTANT, true>(a, s);
+        case CT_STD_MULTIPLIER: return lin_launch_rgb<T, INTERP, CT_STD_MULTIPLIER, true>(a, s);
+    }
+    return CT_ERR_UNSUPPORTED;  // explicit std stacks with interleaved frames go through the element-wise kernel
+}
+
+template <typename T>
+static int lin_dispatch_rgb(const LinArgs &a, int interp, int std_mode, bool write_std, hipStream_t s)
+{
+    switch (interp) {
+        case CT_INTERP_LOOKUP: return lin_dispatch_rgb_std<T, CT_INTERP_LOOKUP>(a, std_mode, write_std, s);
+        case CT_INTERP_LINEAR: return lin_dispatch_rgb_std<T, CT_INTERP_LINEAR>(a, std_mode, write_std, s);
+        case CT_INTERP_CATMULL: return lin_dispatch_rgb_std<T, CT_INTERP_CATMULL>(a, std_mode, write_std, s);
+        case CT_INTERP_NONE: return lin_dispatch_rgb_std<T, CT_INTERP_NONE>(a, std_mode, write_std, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
 template <typename T, int V, int INTERP, int STD, bool WRITE_STD>
 static int lin_launch(const LinArgs &a, hipStream_t s)
 {
@@ -182,8 +309,15 @@ static int lin_typed(LinArgs a, uint32_t Q, int interp, int std_mode, bool write
     auto aligned = [](const void *p, size_t b) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % b) == 0; };
     const bool vec_ok = aligned(a.frames, sizeof(T) * V) && (a.image_stride % V) == 0 && aligned(a.std_stack, 4 * V) &&
                         aligned(a.lin_out, 4 * V) && aligned(a.std_out, 4 * V);
-    const uint32_t q_vec = vec_ok ? (Q / V) * V : 0;
+    uint32_t q_vec = vec_ok ? (Q / V) * V : 0;
     int rc = CT_OK;
+    // interleaved RGB / BGR with whole packets of four pixels per plane: the pixel-owning kernel (packet stores)
+    if (a.tile.layout != CT_LAYOUT_NCHW && a.channels == 3 && std_mode != CT_STD_EXPLICIT && a.tile.plane_local % 4 == 0 &&
+        aligned(a.frames, 16) && (a.image_stride % 4) == 0 && aligned(a.lin_out, 16) && aligned(a.std_out, 16) && a.out_stride % 4 == 0) {
+        a.q_begin = 0;
+        a.q_count = Q;  // 3 * plane_local: a multiple of 12
+        return lin_dispatch_rgb<T>(a, interp, std_mode, write_std, s);
+    }
     if (q_vec) {
         a.q_begin = 0;
         a.q_count = q_vec;

@@ -702,6 +702,16 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     r += inc;
                     r = r >= C ? r - C : r;
                 }
+            } else if (C == 3) {
+                // interleaved RGB / BGR: constant divisors (channel = m % 3, pixel = m / 3, row = global index % 3)
+                const uint32_t plane_g = a.tile.plane_local + a.tile.chan_skip;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    uint32_t c, pixel;
+                    a.tile.interleaved3(q0 + e, c, pixel);
+                    const uint32_t qg = c * plane_g + a.tile.base + pixel;
+                    row_off[e] = (int)(kLookup ? c : qg % 3u) * E * 8;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
@@ -723,6 +733,16 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 
         // loads are addressed as (wave-uniform exposure base) + (32-bit per-thread byte offset): no 64-bit VALU address math
         const uint32_t voff = q0 * (uint32_t)sizeof(T), svoff = q0 * 4u;
+        // planar (state / output) index of memory element m: the identity for planar stacks, constant divisors for RGB / BGR
+        auto planar_of = [&](uint32_t m) -> uint32_t {
+            if (planar) return m;
+            if (C == 3) {
+                uint32_t c, pixel;
+                a.tile.interleaved3(m, c, pixel);
+                return c * a.tile.plane_local + pixel;
+            }
+            return a.tile.planar_index(m);
+        };
 
         // ---- pivot: the running mean of the earlier batches, else the middle exposure's sample ----
         constexpr int VS = FIRST ? 1 : V;  // state registers exist only when there is state
@@ -782,7 +802,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             } else {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    const uint32_t q = a.tile.planar_index(q0 + e);
+                    const uint32_t q = planar_of(q0 + e);
                     meanA[e] = a.mean_state[q];
                     WA[e] = a.sumw_state[q];
                     if constexpr (kHasStd) varA[e] = a.var_state[q];
@@ -1029,7 +1049,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         if (keep_state) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const uint32_t q = a.tile.planar_index(q0 + e);
+                const uint32_t q = planar_of(q0 + e);
                 a.mean_state[q] = mean_o[e];
                 a.sumw_state[q] = Wt_o[e];
                 if constexpr (kHasStd) a.var_state[q] = var_o[e];
@@ -1038,7 +1058,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         if (finalize && !planar) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const uint32_t q = a.tile.planar_index(q0 + e);
+                const uint32_t q = planar_of(q0 + e);
                 if (a.flags & CT_MERGE_MEAN_OUT_F32)
                     static_cast<float *>(a.mean_out)[q] = (float)mean_o[e];
                 else
