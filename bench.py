@@ -318,7 +318,8 @@ def run_linearize(args, rank, world, dev):
                                    f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, ct_linearize_std"},
             "roofline": {"bound": "hbm", "achieved": round(bytes_alg / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic("linearize_c4") if args.frames == 64 else None}}
+                         "traffic": measured_traffic("linearize_c4") if args.frames == 64 else None},
+            **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_linearize(min(args.cpu_seconds, 10.0))})}
 
 
 def run_linearize_streamed(args, dev):
@@ -483,8 +484,162 @@ def run_video(args, rank, world, dev):
             "roofline": _hbm_roofline(bytes_alg, kernel_ms)}
 
 
+def cpu_baseline_train(seconds=12.0, n_exp=8, size=96):
+    """One training step of the eager-PyTorch restatement (forward, float64 residuals over all pairs, autograd into the
+    LUT, penalties) on host cores: SURVEY 8(d) times C3's CPU baseline at batch_size 8 (P <= 28) because the eager path
+    needs > 100 B per pair-pixel."""
+    from clair_torch_amd.datasets import synthetic_exposure_stack
+    from oracle import eager_torch as oe
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    codes, exposures = synthetic_exposure_stack(n_exp, 3, size, size, bits=16, stops_per_step=0.125, seed=1237)
+    x = codes.to(torch.int32).to(torch.float32) / 65535.0
+    t = torch.tensor(exposures, dtype=torch.float64)
+    lut = torch.stack([torch.linspace(0, 1, 256) ** 2.5 for _ in range(3)]).requires_grad_(True)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        loss, _, sp = oe.training_loss(x, None, t, lut, "linear", 0.25, 1 / 255, 254 / 255, True, False, 10.0, 1.0, 1.0, 1.0)
+        torch.autograd.grad(loss.sum(), lut)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 400:
+            break
+    pairs = int(sp.shape[0])
+    return {"value": round(done / el, 3), "unit": "iters/s", "cores": threads, "kind": "port",
+            "pair_pixels_per_s": round(done * pairs * 3 * size * size / el / 1e6, 2),
+            "sample": f"{done} step(s) of oracle/eager_torch.training_loss + autograd on a {n_exp}x{size}x{size}x3 float32 stack "
+                      f"({pairs} pairs; the full C3 shape has 888 pairs x 12.6 M elements and does not fit the eager path), {el:.1f} s"}
+
+
+def cpu_baseline_linearize(seconds=10.0):
+    """oracle/eager_torch.linearize_frame (forward + autograd.grad per frame, as the reference) on 1920x1080x3 frames."""
+    from oracle import eager_torch as oe
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(5)
+    frame = torch.randint(0, 65536, (3, 1080, 1920), generator=gen, dtype=torch.int32).to(torch.float32) / 65535.0
+    lut = make_lut("cpu")
+    sd = frame * 0.05
+    done, t0 = 0, time.perf_counter()
+    while True:
+        oe.linearize_frame(frame, sd, lut, "linear")
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 200:
+            break
+    return {"value": round(done / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{done} frame(s) 1920x1080x3 float32 through oracle/eager_torch.linearize_frame (forward + autograd.grad), {el:.1f} s"}
+
+
+def run_train_through_api(args, rank, world, dev):
+    """BASELINE configuration C3 AS STATED: `--steps` epochs (500 in BASELINE) of train_icrf itself on the device-resident
+    64 x 2048 x 2048 x 3 stack -- DataLoader + custom_collate, per-channel fused Adam (lr 1e-3), ReduceLROnPlateau(0.5, 50),
+    alpha, beta, gamma, delta = 10, 1, 1, 1, relative loss, no uncertainty weighting, ratio threshold 0.25
+    (scripts/run_icrf_model_training.py:49-69, scripts/config.yaml:31-34).  Also: the same call on a down-scaled copy
+    against the eager oracle trained the same way on the CPU (final LUT)."""
+    from torch.utils.data import DataLoader
+    from clair_torch_amd.common.enums import InterpMode
+    from clair_torch_amd.common.transforms import CastTo, Normalize
+    from clair_torch_amd.datasets import StackDataset, custom_collate, synthetic_exposure_stack
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.training import train_icrf
+    n_exp, size = args.train_exposures, args.train_size
+    tf = [CastTo("float32"), Normalize(max_val=65535, min_val=0)]
+
+    def fit(codes, exposures, epochs, device):
+        model = ICRFModelDirect(n_points=256, channels=3, interpolation_mode=InterpMode.LINEAR, initial_power=2.5).to(device)
+        opts = [torch.optim.Adam(model.channel_params(c), lr=1e-3, fused=True) for c in range(3)]
+        scheds = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode="min", factor=0.5, patience=50) for o in opts]
+        ds = StackDataset(codes, exposures)
+        loader = DataLoader(ds, batch_size=len(exposures), shuffle=False, collate_fn=custom_collate)
+        train_icrf(loader, len(exposures), device, model, optimizers=opts, schedulers=scheds, use_relative_linearity_loss=True,
+                   use_uncertainty_weighting=False, epochs=epochs, patience=10 ** 9, alpha=10.0, beta=1.0, gamma=1.0, delta=1.0,
+                   lower_valid_threshold=1 / 255, upper_valid_threshold=254 / 255, exposure_ratio_threshold=0.25,
+                   gpu_transforms=tf, verbose=False)
+        return model
+
+    codes, exposures = synthetic_exposure_stack(n_exp, 3, size, size, bits=16, stops_per_step=0.125, seed=1237, device=dev)
+    fit(codes, exposures, max(2, args.warmup), dev)  # code objects, pair tables, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fit(codes, exposures, args.steps, dev)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # kernel share: the two launches of a step timed back to back without the host loop around them
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.training import linearity_loss
+    t = torch.tensor(exposures, dtype=torch.float64)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n_exp, dev)
+    lut = torch.stack([torch.linspace(0, 1, 256) ** 2.5 for _ in range(3)]).to(dev).requires_grad_(True)
+
+    def kernels():
+        lin, _ = linearity_loss(lut, codes, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True, use_unc_weight=False)
+        torch.autograd.grad(lin.sum(), lut)
+
+    for _ in range(3):
+        kernels()
+    torch.cuda.synchronize()
+    k0 = time.perf_counter()
+    for _ in range(20):
+        kernels()
+    torch.cuda.synchronize()
+    kernel_ms = (time.perf_counter() - k0) / 20 * 1e3
+    del codes
+    torch.cuda.empty_cache()
+    # final LUT against the eager oracle on a down-scaled copy (same optimiser / scheduler recipe on the CPU)
+    small, exp_s = synthetic_exposure_stack(16, 3, 48, 48, bits=16, stops_per_step=0.5, seed=1241)
+    ep = 40
+    got = fit(small.to(dev), exp_s, ep, dev).icrf.detach().cpu()
+    want = _oracle_training_run(small, exp_s, ep)
+    out = {"metric": "ICRF training iterations/s (train_icrf through the public API)", "unit": "iters/s",
+           "value": round(args.steps / elapsed, 3), "n_gpus": 1, "steps": args.steps, "warmup": max(2, args.warmup),
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"C3 as stated: {args.steps} epochs of train_icrf, {n_exp}-exposure {size}x{size}x3 uint16 stack resident in HBM, "
+                                  f"{pairs.n_pairs} pairs, relative loss, per-channel fused Adam + ReduceLROnPlateau(0.5, 50), "
+                                  "alpha, beta, gamma, delta = 10, 1, 1, 1",
+                      "kernel_ms_per_step": round(kernel_ms, 3),
+                      "host_and_small_kernels_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 3),
+                      "final_lut_vs_eager_oracle": {"stack": "16x48x48x3 uint16", "epochs": ep,
+                                                    "max_abs_diff": float((got - want).abs().max()),
+                                                    "max_abs_change_from_start": float((want - torch.stack([torch.linspace(0, 1, 256) ** 2.5] * 3)).abs().max())}},
+           "roofline": _train_roofline(pairs.n_pairs, 3 * size * size, elapsed / args.steps)}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_train(args.cpu_seconds)
+    return out
+
+
+def _oracle_training_run(codes, exposures, epochs):
+    """The reference's training recipe on the eager oracle (CPU): per-channel Adam (lr 1e-3), ReduceLROnPlateau(0.5, 50),
+    alpha 10; first step dead as in the reference (the curve only becomes a function of the parameters after the first
+    update_icrf, icrf_training.py:92-156)."""
+    from oracle import eager_torch as oe
+    x = codes.to(torch.int32).to(torch.float32) / 65535.0
+    t = torch.tensor(exposures, dtype=torch.float64)
+    params = [torch.nn.Parameter(torch.linspace(0, 1, 256) ** 2.5) for _ in range(3)]
+    opts = [torch.optim.Adam([p], lr=1e-3) for p in params]
+    scheds = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode="min", factor=0.5, patience=50) for o in opts]
+    for epoch in range(epochs):
+        for o in opts:
+            o.zero_grad()
+        curve = torch.stack(list(params))
+        loss, _, _ = oe.training_loss(x, None, t, curve, "linear", 0.25, 1 / 255, 254 / 255, True, False, 10.0, 1.0, 1.0, 1.0)
+        if epoch > 0:  # the dead first step: no gradient reaches the parameters, Adam steps on None grads do nothing
+            for c in range(3):
+                loss[c].backward(retain_graph=True)
+            for o in opts:
+                o.step()
+        for c, sc in enumerate(scheds):
+            sc.step(float(loss[c].detach()))
+    return torch.stack([p.detach() for p in params])
+
+
 def run_train(args, rank, world, dev):
     """C3: one train_icrf optimizer step (forward sums + LUT gradient + Adam) on a 64-exposure 2048x2048x3 stack."""
+    if args.through_api:
+        return run_train_through_api(args, rank, world, dev)
     from clair_torch_amd import ops
     from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
     from clair_torch_amd.datasets import synthetic_exposure_stack
@@ -521,7 +676,8 @@ def run_train(args, rank, world, dev):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: {n_exp}-exposure {h}x{w}x3 uint16 stack, {pairs.n_pairs} pairs, relative loss"},
-            "roofline": _train_roofline(pairs.n_pairs, 3 * h * w, elapsed / args.steps)}
+            "roofline": _train_roofline(pairs.n_pairs, 3 * h * w, elapsed / args.steps),
+            **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_train(args.cpu_seconds)})}
 
 
 def _train_roofline(n_pairs, elements, seconds):
@@ -597,6 +753,9 @@ def main():
     ap.add_argument("--streamed", action="store_true",
                     help="linearize: end to end, --stream-frames frames from pinned host memory through the drop-in generator")
     ap.add_argument("--stream-frames", type=int, default=1024)
+    ap.add_argument("--through-api", action="store_true",
+                    help="train: BASELINE C3 as stated -- --steps epochs of train_icrf itself (DataLoader, per-channel fused Adam, "
+                         "ReduceLROnPlateau, penalties) instead of the two kernels + Adam")
     ap.add_argument("--train-exposures", type=int, default=64)
     ap.add_argument("--train-size", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -95,8 +95,12 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
                 if loss.ndim == 0:
                     loss.backward()
                 else:
-                    for c in range(len(optimizers)):
-                        loss[c].backward(retain_graph=True)
+                    # The reference calls loss[c].backward(retain_graph=True) per channel (icrf_training.py:148-149); the
+                    # gradients ACCUMULATE in the same parameter .grad tensors (every loss[c] reaches every LUT row through
+                    # the p % C row rule), so what the optimisers see is d(sum_c loss[c]) / d parameters -- one backward
+                    # of the sum: one ct_pair_residual_bwd launch instead of three whole-stack launches with two thirds
+                    # of their coefficients zero.
+                    loss[:len(optimizers)].sum().backward()
             for optimizer in optimizers:
                 optimizer.step()
             icrf_model.update_icrf()
