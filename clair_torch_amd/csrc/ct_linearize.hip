@@ -305,7 +305,13 @@ static int lin_dispatch(const LinArgs &a, int interp, int std_mode, bool write_s
 template <typename T>
 static int lin_typed(LinArgs a, uint32_t Q, int interp, int std_mode, bool write_std, hipStream_t s)
 {
-    constexpr int V = 16 / sizeof(T) > 8 ? 8 : 16 / sizeof(T);
+    // Elements per thread: 16 integer codes (four typed loads in flight) or 8 float pixels (two 16-byte loads).  The
+    // pixel-owning RGB kernel (12 codes per thread, three loads in flight) ran C4 at 0.68 ms where the 8-code planar
+    // mapping took 0.85 ms (profiles/r03_layout_ingest.md): the write-heavy stream wants more bytes in flight per thread.
+#ifndef CT_LINEARIZE_V_INT
+#define CT_LINEARIZE_V_INT 16
+#endif
+    constexpr int V = sizeof(T) == 4 ? 8 : CT_LINEARIZE_V_INT;
     auto aligned = [](const void *p, size_t b) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % b) == 0; };
     const bool vec_ok = aligned(a.frames, sizeof(T) * V) && (a.image_stride % V) == 0 && aligned(a.std_stack, 4 * V) &&
                         aligned(a.lin_out, 4 * V) && aligned(a.std_out, 4 * V);
