@@ -604,6 +604,8 @@ def run_train_through_api(args, rank, world, dev):
                       "host_and_small_kernels_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 3),
                       "final_lut_vs_eager_oracle": {"stack": "16x48x48x3 uint16", "epochs": ep,
                                                     "max_abs_diff": float((got - want).abs().max()),
+                                                    "mean_abs_diff": float((got - want).abs().mean()),
+                                                    "bins_off_by_more_than_1e-4": int(((got - want).abs() > 1e-4).sum()),
                                                     "max_abs_change_from_start": float((want - torch.stack([torch.linspace(0, 1, 256) ** 2.5] * 3)).abs().max())}},
            "roofline": _train_roofline(pairs.n_pairs, 3 * size * size, elapsed / args.steps)}
     if not args.no_cpu_baseline:

@@ -53,12 +53,36 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
     const float top = (float)(L - 1);
     int row_off[V];
+    if (a.tile.layout == CT_LAYOUT_NCHW) {
+        // planar frames: the channel by comparisons, the row of the first element by ONE modulo (a constant divisor for
+        // C == 3), the following elements by an add and a conditional subtract -- runtime 32-bit divisions cost ~30
+        // instructions each, and two of them per element were a third of this kernel's arithmetic
+        int ch = 0;
+        for (int c = 1; c < C; ++c) ch += q0 >= (uint32_t)c * a.tile.plane_local ? 1 : 0;
+        const uint32_t qg = q0 + (uint32_t)ch * a.tile.chan_skip + a.tile.base;
+        uint32_t off = q0 - (uint32_t)ch * a.tile.plane_local;
+        int r = C == 3 ? (int)(qg % 3u) : (int)(qg % (uint32_t)C);
+        const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-        int ch;
-        uint32_t qg;
-        a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
-        row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
+        for (int e = 0; e < V; ++e) {
+            row_off[e] = (INTERP == CT_INTERP_LOOKUP ? ch : r) * L * kEntry;
+            int inc = 1;
+            if (++off == a.tile.plane_local) {
+                off = 0;
+                ++ch;
+                inc += skip_mod;
+            }
+            r += inc;
+            r = r >= C ? r - C : r;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int ch;
+            uint32_t qg;
+            a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
+            row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
+        }
     }
     for (uint32_t f = blockIdx.y; f < a.n_frames; f += gridDim.y) {
         const int64_t off = (int64_t)f * a.image_stride + q0;
@@ -305,11 +329,11 @@ static int lin_dispatch(const LinArgs &a, int interp, int std_mode, bool write_s
 template <typename T>
 static int lin_typed(LinArgs a, uint32_t Q, int interp, int std_mode, bool write_std, hipStream_t s)
 {
-    // Elements per thread: 16 integer codes (four typed loads in flight) or 8 float pixels (two 16-byte loads).  The
-    // pixel-owning RGB kernel (12 codes per thread, three loads in flight) ran C4 at 0.68 ms where the 8-code planar
-    // mapping took 0.85 ms (profiles/r03_layout_ingest.md): the write-heavy stream wants more bytes in flight per thread.
+    // Elements per thread: 8 integer codes (two typed loads) or 8 float pixels (two 16-byte loads).  16 codes per thread was
+    // measured 2.6x SLOWER on C4 (2.21 against 0.85 ms, profiles/r03_layout_ingest.md) although the pixel-owning RGB kernel
+    // with 12 codes per thread is the fastest of all (0.68 ms).
 #ifndef CT_LINEARIZE_V_INT
-#define CT_LINEARIZE_V_INT 16
+#define CT_LINEARIZE_V_INT 8
 #endif
     constexpr int V = sizeof(T) == 4 ? 8 : CT_LINEARIZE_V_INT;
     auto aligned = [](const void *p, size_t b) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % b) == 0; };

@@ -537,6 +537,10 @@ struct PivotArgs {
     int32_t batch_size[16];                     // exposures per batch; a.batch = their sum, a.exposure in the same order
     const void *batch_ptr[16];                  // each batch's (B_b, C, H_tile, W) stack
     const float *std_ptr[16];                   // CT_STD_EXPLICIT: each batch's std stack
+    // interleaved RGB / BGR input with planar packet stores (see the kernel's epilogue): every wavefront owns 252
+    // consecutive memory elements = 84 whole pixels (lane 63 idles), results regrouped by plane through `stage_off`
+    int32_t rgb252;
+    uint32_t stage_off;                         // LDS byte offset of the 4 x 3072-byte staging areas
 };
 constexpr int kMaxMultiBatches = 16;
 constexpr int kPivotV = 4;  // elements per thread of merge_pivot_kernel (uint16: 8-byte loads, uint8: 4-byte)
@@ -565,17 +569,18 @@ constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which
 // wavefronts measure the same within 1 % (0.856 / 0.865 ms sustained, profiles/r02_typed_load_ab.log).  Raw-code
 // builds (CT_PIVOT_TYPED_LOAD=0) fit 64.  The state-carrying kernels keep the default allocation.
 #ifndef CT_PIVOT_KERNEL_ATTR
-#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? 7 : 8) : 4, 8)))
+#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? (RGB252 ? 6 : 7) : 8) : 4, 8)))
 #endif
 // MULTI: the launch walks x.n_batches consecutive batches per element with (mean, sum of weights, variance) in registers and
 // the per-batch recurrence of WBOMean (statistics.py:64-109, state detached after every batch, hdr_merge.py:128) applied
 // between them -- bit for bit what one launch per batch gives (the first-batch arithmetic with zero state IS the
 // state-carrying arithmetic: W_A = 0 makes frac = 1 and gamma = 0 exactly), without the 32 B per element and batch of
 // state traffic the reference's default batch_size: 4 costs beside 8 B of samples.
-template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST, bool CLAMP = false, bool MULTI = false>
+template <typename T, int V, int INTERP, int WEIGHT, int STD, bool FIRST, bool CLAMP = false, bool MULTI = false, bool RGB252 = false>
 __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kernel(const MergeArgs a, const PivotArgs x)
 {
     static_assert(!MULTI || (!FIRST && CT_PIVOT_TYPED_LOAD), "MULTI carries state and uses the typed loads");
+    static_assert(!RGB252 || (V == 4 && FIRST && !MULTI && CT_PIVOT_TYPED_LOAD), "RGB252: single-batch packets of the typed-load kernel");
     extern __shared__ __align__(16) char lds[];
     static_assert(sizeof(T) != 4, "raw integer codes only");
     static_assert(INTERP != CT_INTERP_CATMULL, "CATMULL uses merge_kernel / merge_reference_order_kernel");
@@ -674,10 +679,19 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     [[maybe_unused]] float floor_magic = kFloorMagic;
     asm volatile("" : "+v"(floor_magic));  // one VGPR for the whole kernel (a VOP3 FMA cannot carry a literal)
 
+    constexpr bool rgb252 = RGB252;  // interleaved RGB / BGR with packet stores: its own instantiation (the regrouping costs
+                                     // registers the planar headline kernel, capped at 72, does not have)
     for (uint32_t tile = blockIdx.x; tile < x.n_tiles; tile += gridDim.x) {
-        const uint32_t vec = tile * (uint32_t)kBlock + threadIdx.x;
-        if (vec * (uint32_t)V >= a.q_count) continue;  // ragged last tile (no barrier below: lanes may leave)
-        const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
+        uint32_t vec = tile * (uint32_t)kBlock + threadIdx.x;
+        uint32_t q0 = a.q_begin + vec * (uint32_t)V;
+        if (rgb252) {
+            // wavefront W of the launch owns memory elements [252 W, 252 W + 252): 21 lane triples = 84 whole pixels
+            const uint32_t lane = threadIdx.x & 63u, first = (tile * 4u + (threadIdx.x >> 6)) * 252u + lane * 4u;
+            if (lane == 63u || first >= a.q_count) continue;
+            q0 = a.q_begin + first;
+        } else if (vec * (uint32_t)V >= a.q_count) {
+            continue;  // ragged last tile (no barrier below: lanes may leave)
+        }
 
         int row_off[V];  // byte offset of each element's LUT row inside the LDS table
         if constexpr (kLut) {
@@ -1004,10 +1018,14 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     mean_o[e] = (double)p[e] + (double)q;
                 } else {
                     Wt = WA[e] + Wb;
-                    frac = Wb / Wt;  // float32 division (statistics.py:105)
+                    // 1 / W_t by v_rcp_f32 + one Newton step (<= 1 ulp) instead of two IEEE divisions (~20 instructions):
+                    // with several batches per launch this epilogue runs once per batch and element (statistics.py:105)
+                    float rw = __builtin_amdgcn_rcpf(Wt);
+                    rw = rw * __builtin_fmaf(-Wt, rw, 2.0f);
+                    frac = Wb * rw;
                     const double diff = ((double)p[e] - meanA[e]) + (double)q;  // m_b - mean_A
                     mean_o[e] = __builtin_fma((double)frac, diff, meanA[e]);
-                    gam = (WA[e] / (Wt * Wt)) * (float)diff;
+                    gam = ((WA[e] * rw) * rw) * (float)diff;
                     var = varA[e];
                 }
                 Wt_o[e] = Wt;
@@ -1055,7 +1073,41 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 if constexpr (kHasStd) a.var_state[q] = var_o[e];
             }
         }
-        if (finalize && !planar) {
+        if (finalize && rgb252) {
+            if constexpr (RGB252) {
+                // Regroup the wavefront's 252 results by channel plane through LDS (wave-private, DS operations of one
+                // wavefront execute in order: no barrier): lane 3 i + c then holds pixels 4 i .. 4 i + 3 of plane c and
+                // writes them as 16-byte packets, instead of twelve 8- / 4-byte stores scattered over three planes.
+                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+                char *stage = lds + x.stage_off + wave * 3072u;
+                double *sm = reinterpret_cast<double *>(stage);            // 252 means in memory order
+                float *ss = reinterpret_cast<float *>(stage + 2048);       // 252 standard uncertainties
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                d2 m01 = {mean_o[0], mean_o[1]}, m23 = {mean_o[2], mean_o[3]};
+                *reinterpret_cast<d2 *>(sm + 4u * lane) = m01;
+                *reinterpret_cast<d2 *>(sm + 4u * lane + 2) = m23;
+                if constexpr (kHasStd) {
+                    f4 sv = {__builtin_amdgcn_sqrtf(var_o[0]), __builtin_amdgcn_sqrtf(var_o[1]), __builtin_amdgcn_sqrtf(var_o[2]),
+                             __builtin_amdgcn_sqrtf(var_o[3])};
+                    *reinterpret_cast<f4 *>(ss + 4u * lane) = sv;
+                }
+                const uint32_t tri = lane / 3u, c = lane - 3u * tri;       // plane c, pixels 4 tri .. 4 tri + 3 of this wavefront
+                const uint32_t cm = a.tile.layout == CT_LAYOUT_NHWC_BGR ? 2u - c : c;
+                const uint32_t pix0 = (q0 - 4u * lane - a.q_begin) / 3u + 4u * tri;   // (wavefront base is a multiple of 252)
+                Packet<double, 4> mo;
+                Packet<float, 4> so;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t m = 3u * (4u * tri + (uint32_t)j) + cm;
+                    mo.v[j] = sm[m];
+                    if constexpr (kHasStd) so.v[j] = ss[m];
+                }
+                const size_t dst = (size_t)c * a.tile.plane_local + pix0;
+                store_stream(reinterpret_cast<Packet<double, 4> *>(static_cast<double *>(a.mean_out) + dst), mo);
+                if constexpr (kHasStd) store_stream(reinterpret_cast<Packet<float, 4> *>(a.std_out + dst), so);
+            }
+        } else if (finalize && !planar) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const uint32_t q = planar_of(q0 + e);
@@ -1124,9 +1176,29 @@ static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
         x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
         constexpr bool kTable = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;
         constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && CT_PIVOT_TYPED_LOAD && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;
-        const size_t lds = (kTable ? (size_t)a.channels * x.n_entries * (kWV == 2 ? 16 : 8) : 0) +
-                           2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
+        size_t lds = (kTable ? (size_t)a.channels * x.n_entries * (kWV == 2 ? 16 : 8) : 0) +
+                     2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
+        x.rgb252 = 0;
+        if constexpr (V == 4 && CT_PIVOT_TYPED_LOAD) {
+            // interleaved RGB / BGR, the whole image in this launch, outputs only (no streaming state): packet stores
+            auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; };
+            if (a.tile.layout != CT_LAYOUT_NCHW && a.channels == 3 && a.tile.plane_local % 4 == 0 && !a.mean_state &&
+                (a.flags & CT_MERGE_FINALIZE) && !(a.flags & CT_MERGE_MEAN_OUT_F32) && a.q_begin == 0 &&
+                a.q_count == 3u * a.tile.plane_local && aligned16(a.mean_out) && aligned16(a.std_out)) {
+                x.rgb252 = 1;
+                x.n_tiles = (a.q_count + 1007u) / 1008u;
+                lds = (lds + 15) & ~(size_t)15;
+                x.stage_off = (uint32_t)lds;
+                lds += 4 * 3072;
+            }
+        }
         if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+        if constexpr (V == 4 && CT_PIVOT_TYPED_LOAD) {
+            if (x.rgb252)
+                return (a.flags & CT_MERGE_FIRST_BATCH)
+                           ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true, CLAMP, false, true>>(a, x, lds, stream)
+                           : CT_ERR_INVALID_ARGUMENT;  // (no state and not the first batch: refused earlier)
+        }
         return (a.flags & CT_MERGE_FIRST_BATCH)
                    ? launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, true, CLAMP>>(a, x, lds, stream)
                    : launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false, CLAMP>>(a, x, lds, stream);
