@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     // with several batches per launch this epilogue runs once per batch and element (statistics.py:105)
                     float rw = __builtin_amdgcn_rcpf(Wt);
                     rw = rw * __builtin_fmaf(-Wt, rw, 2.0f);
-                    frac = Wb * rw;
+                    frac = WA[e] == 0.0f ? 1.0f : Wb * rw;  // (a fresh merge inside a MULTI launch: W_A = 0, W_B / W_B = 1 exactly)
                     const double diff = ((double)p[e] - meanA[e]) + (double)q;  // m_b - mean_A
                     mean_o[e] = __builtin_fma((double)frac, diff, meanA[e]);
                     gam = ((WA[e] * rw) * rw) * (float)diff;

@@ -35,7 +35,7 @@ corr = S * 2 / (stream["FETCH_SIZE"] * 1024)
 print("calibration on stream_only<4>: %.4f GB read -> FETCH_SIZE correction x%.4f; WRITE_SIZE %.4f GB for %.4f GB written"
       % (S * 2 / 1e9, corr, stream["WRITE_SIZE"] * 1024 / 1e9, Q * 12 / 1e9))
 for k, v in res.items():
-    if "merge_pivot_kernel<unsigned short, 4, 1, 1, 2, true>" in k or "merge_kernel<unsigned short, 4, 1, 1, 2" in k:
+    if "merge_pivot_kernel<unsigned short, 4, 1, 1, 2, true" in k or "merge_kernel<unsigned short, 4, 1, 1, 2" in k:
         rd, wr = v["FETCH_SIZE"] * 1024 * corr, v["WRITE_SIZE"] * 1024
         print(k[-64:], "read %.4f GB + written %.4f GB = %.4f GB (algorithmic %.4f GB)" % (rd / 1e9, wr / 1e9, (rd + wr) / 1e9, (S * 2 + Q * 12) / 1e9))
         json.dump({"kernel": k, "fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "fetch_correction": corr,
