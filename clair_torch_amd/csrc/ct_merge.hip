@@ -537,8 +537,8 @@ struct PivotArgs {
     int32_t batch_size[16];                     // exposures per batch; a.batch = their sum, a.exposure in the same order
     const void *batch_ptr[16];                  // each batch's (B_b, C, H_tile, W) stack
     const float *std_ptr[16];                   // CT_STD_EXPLICIT: each batch's std stack
-    // interleaved RGB / BGR input with planar packet stores (see the kernel's epilogue): every wavefront owns 252
-    // consecutive memory elements = 84 whole pixels (lane 63 idles), results regrouped by plane through `stage_off`
+    // interleaved RGB / BGR input with planar packet stores (see the kernel's epilogue): the results of a wavefront are
+    // regrouped by channel plane through its 3 KB staging area at `stage_off`
     int32_t rgb252;
     uint32_t stage_off;                         // LDS byte offset of the 4 x 3072-byte staging areas
 };
@@ -682,16 +682,9 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     constexpr bool rgb252 = RGB252;  // interleaved RGB / BGR with packet stores: its own instantiation (the regrouping costs
                                      // registers the planar headline kernel, capped at 72, does not have)
     for (uint32_t tile = blockIdx.x; tile < x.n_tiles; tile += gridDim.x) {
-        uint32_t vec = tile * (uint32_t)kBlock + threadIdx.x;
-        uint32_t q0 = a.q_begin + vec * (uint32_t)V;
-        if (rgb252) {
-            // wavefront W of the launch owns memory elements [252 W, 252 W + 252): 21 lane triples = 84 whole pixels
-            const uint32_t lane = threadIdx.x & 63u, first = (tile * 4u + (threadIdx.x >> 6)) * 252u + lane * 4u;
-            if (lane == 63u || first >= a.q_count) continue;
-            q0 = a.q_begin + first;
-        } else if (vec * (uint32_t)V >= a.q_count) {
-            continue;  // ragged last tile (no barrier below: lanes may leave)
-        }
+        const uint32_t vec = tile * (uint32_t)kBlock + threadIdx.x;
+        if (vec * (uint32_t)V >= a.q_count) continue;  // ragged last tile (no barrier below: lanes may leave)
+        const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
 
         int row_off[V];  // byte offset of each element's LUT row inside the LDS table
         if constexpr (kLut) {
@@ -1075,37 +1068,56 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         }
         if (finalize && rgb252) {
             if constexpr (RGB252) {
-                // Regroup the wavefront's 252 results by channel plane through LDS (wave-private, DS operations of one
-                // wavefront execute in order: no barrier): lane 3 i + c then holds pixels 4 i .. 4 i + 3 of plane c and
-                // writes them as 16-byte packets, instead of twelve 8- / 4-byte stores scattered over three planes.
+                // Regroup the wavefront's results by channel plane through LDS (wave-private; the DS operations of one
+                // wavefront execute in order, so no barrier): the wavefront's 256 consecutive memory elements contain up to
+                // 21 whole groups of 12 elements = 4 pixels x 3 channels; lane 3 i + c takes plane c of group i and writes
+                // its four consecutive pixels as 16-byte packets.  The <= 11 elements before the first and after the last
+                // whole group are stored one by one by the lanes that own them.  (A mapping that gives every wavefront 252
+                // elements = 84 whole pixels was measured first: its 504-byte wave loads cost 11 % more HBM fetch.)
                 const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
                 char *stage = lds + x.stage_off + wave * 3072u;
-                double *sm = reinterpret_cast<double *>(stage);            // 252 means in memory order
-                float *ss = reinterpret_cast<float *>(stage + 2048);       // 252 standard uncertainties
+                double *sm = reinterpret_cast<double *>(stage);            // 256 means in memory order
+                float *ss = reinterpret_cast<float *>(stage + 2048);       // 256 standard uncertainties
                 typedef double d2 __attribute__((ext_vector_type(2)));
                 typedef float f4 __attribute__((ext_vector_type(4)));
+                float sdv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sdv[e] = kHasStd ? __builtin_amdgcn_sqrtf(var_o[e]) : 0.0f;
                 d2 m01 = {mean_o[0], mean_o[1]}, m23 = {mean_o[2], mean_o[3]};
                 *reinterpret_cast<d2 *>(sm + 4u * lane) = m01;
                 *reinterpret_cast<d2 *>(sm + 4u * lane + 2) = m23;
                 if constexpr (kHasStd) {
-                    f4 sv = {__builtin_amdgcn_sqrtf(var_o[0]), __builtin_amdgcn_sqrtf(var_o[1]), __builtin_amdgcn_sqrtf(var_o[2]),
-                             __builtin_amdgcn_sqrtf(var_o[3])};
+                    f4 sv = {sdv[0], sdv[1], sdv[2], sdv[3]};
                     *reinterpret_cast<f4 *>(ss + 4u * lane) = sv;
                 }
-                const uint32_t tri = lane / 3u, c = lane - 3u * tri;       // plane c, pixels 4 tri .. 4 tri + 3 of this wavefront
-                const uint32_t cm = a.tile.layout == CT_LAYOUT_NHWC_BGR ? 2u - c : c;
-                const uint32_t pix0 = (q0 - 4u * lane - a.q_begin) / 3u + 4u * tri;   // (wavefront base is a multiple of 252)
-                Packet<double, 4> mo;
-                Packet<float, 4> so;
+                const uint32_t wave_first = q0 - 4u * lane - a.q_begin;    // first memory element of this wavefront
+                const uint32_t wave_end = wave_first + 256u < a.q_count ? wave_first + 256u : a.q_count;
+                const uint32_t g_first = (wave_first + 11u) / 12u, g_end = wave_end / 12u;   // whole groups [g_first, g_end)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t m = 3u * (4u * tri + (uint32_t)j) + cm;
-                    mo.v[j] = sm[m];
-                    if constexpr (kHasStd) so.v[j] = ss[m];
+                for (int e = 0; e < 4; ++e) {   // the ragged ends of the wavefront's range
+                    const uint32_t m = q0 + (uint32_t)e - a.q_begin;
+                    if (m < 12u * g_first || m >= 12u * g_end) {
+                        const uint32_t q = planar_of(q0 + e);
+                        static_cast<double *>(a.mean_out)[q] = mean_o[e];
+                        if constexpr (kHasStd) a.std_out[q] = sdv[e];
+                    }
                 }
-                const size_t dst = (size_t)c * a.tile.plane_local + pix0;
-                store_stream(reinterpret_cast<Packet<double, 4> *>(static_cast<double *>(a.mean_out) + dst), mo);
-                if constexpr (kHasStd) store_stream(reinterpret_cast<Packet<float, 4> *>(a.std_out + dst), so);
+                const uint32_t tri = lane / 3u, c = lane - 3u * tri;
+                if (g_first + tri < g_end) {
+                    const uint32_t g = g_first + tri;                      // global group: pixels 4 g .. 4 g + 3
+                    const uint32_t cm = a.tile.layout == CT_LAYOUT_NHWC_BGR ? 2u - c : c;
+                    const uint32_t local = 12u * g - wave_first + cm;     // index of (pixel 4 g, memory channel cm) in the stage
+                    Packet<double, 4> mo;
+                    Packet<float, 4> so;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mo.v[j] = sm[local + 3u * (uint32_t)j];
+                        if constexpr (kHasStd) so.v[j] = ss[local + 3u * (uint32_t)j];
+                    }
+                    const size_t dst = (size_t)c * a.tile.plane_local + 4u * (size_t)g;
+                    store_stream(reinterpret_cast<Packet<double, 4> *>(static_cast<double *>(a.mean_out) + dst), mo);
+                    if constexpr (kHasStd) store_stream(reinterpret_cast<Packet<float, 4> *>(a.std_out + dst), so);
+                }
             }
         } else if (finalize && !planar) {
 #pragma unroll
@@ -1186,7 +1198,6 @@ static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
                 (a.flags & CT_MERGE_FINALIZE) && !(a.flags & CT_MERGE_MEAN_OUT_F32) && a.q_begin == 0 &&
                 a.q_count == 3u * a.tile.plane_local && aligned16(a.mean_out) && aligned16(a.std_out)) {
                 x.rgb252 = 1;
-                x.n_tiles = (a.q_count + 1007u) / 1008u;
                 lds = (lds + 15) & ~(size_t)15;
                 x.stage_off = (uint32_t)lds;
                 lds += 4 * 3072;
