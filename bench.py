@@ -162,17 +162,22 @@ def run_merge(args, rank, world, dev):
     init_codes, init_exp = synthetic_exposure_stack(8, c, 8, 8, bits=16, stops_per_step=0.25, seed=1, device=dev)
     ops.hdr_merge_batch(init_codes, torch.tensor(init_exp, dtype=torch.float64, device=dev), lut=lut, interp="linear",
                         gaussian_weight=True, std_mode="multiplier", std_value=0.05)
-    codes, exposures = synthetic_exposure_stack(n_exp, c, h_global, w, bits=16, stops_per_step=0.25, seed=1236,
+    bits = {65535: 16, 16383: 14, 4095: 12, 1023: 10}[args.max_code]   # e.g. 12-bit camera data in a uint16 container
+    codes, exposures = synthetic_exposure_stack(n_exp, c, h_global, w, bits=bits, stops_per_step=0.25, seed=1236,
                                                 device=dev, row_range=(rank * h, (rank + 1) * h))
+    if bits < 16:
+        codes = codes.to(torch.uint16) if codes.dtype != torch.uint16 else codes
     t_dev = torch.tensor(exposures, dtype=torch.float64, device=dev)
     tile = ops.TileGeometry(h_global=h_global, row_offset=rank * h) if world > 1 else None
-    kw = dict(lut=lut, interp="linear", gaussian_weight=True, std_mode="multiplier", std_value=0.05, tile=tile)
+    kw = dict(lut=lut, interp=args.interp, gaussian_weight=True, std_mode="multiplier", std_value=0.05, tile=tile,
+              max_code=float(args.max_code))
     in_bytes = 2
     if args.input == "f32":  # what the reference's own DataLoader delivers: normalised float32 pixels
-        codes = codes.to(torch.int32).to(torch.float32) / 65535.0
+        codes = codes.to(torch.int32).to(torch.float32) / float(args.max_code)
+        kw.pop("max_code")
         in_bytes = 4
     if args.std == "explicit":
-        kw.update(std=(codes.to(torch.float32) * (0.05 / (65535.0 if args.input == "u16" else 1.0))), std_mode="explicit")
+        kw.update(std=(codes.to(torch.float32) * (0.05 / (float(args.max_code) if args.input == "u16" else 1.0))), std_mode="explicit")
         in_bytes += 4
     elif args.std == "none":
         kw.update(std_mode="none")
@@ -235,9 +240,12 @@ def run_merge(args, rank, world, dev):
     # stack (+ explicit std) read + float64 mean (+ float32 std) written
     bytes_alg = n_exp * c * px * in_bytes + c * px * (8 + (0 if args.std == "none" else 4))
     dtype_code = nv.DTYPE_U16 if args.input == "u16" else nv.DTYPE_F32
-    flags = nv.MERGE_FIRST_BATCH | nv.MERGE_FINALIZE | (nv.MERGE_F64_MOMENTS if args.f64_moments else 0)
-    kernel = nv.load().ct_hdr_merge_kernel_name(dtype_code, 65535.0, nv.INTERP_LINEAR, 256, flags).decode()
-    traffic = measured_traffic("merge_c2") if (args.input, args.std, h, w, n_exp) == ("u16", "multiplier", 4096, 4096, 32) else None
+    flags = nv.MERGE_FIRST_BATCH | nv.MERGE_FINALIZE | (nv.MERGE_F64_MOMENTS if args.f64_moments else 0) | \
+        (0 if args.std == "none" else nv.MERGE_STD_HINT)
+    interp_code = {"linear": nv.INTERP_LINEAR, "lookup": nv.INTERP_LOOKUP, "catmull": nv.INTERP_CATMULL}[args.interp]
+    kernel = nv.load().ct_hdr_merge_kernel_name(dtype_code, float(args.max_code), interp_code, 256, flags).decode()
+    traffic = measured_traffic("merge_c2") if (args.input, args.std, h, w, n_exp, args.max_code, args.interp, args.layout) == \
+        ("u16", "multiplier", 4096, 4096, 32, 65535, "linear", "nchw") else None
     name = "C5" if strong else "C2"
     out = {
         "metric": "MPix/s HDR-merged (+uncertainty) at N=32 4K RGB", "value": round(world * px * args.steps / elapsed / 1e6, 1),
@@ -247,7 +255,8 @@ def run_merge(args, rank, world, dev):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU"
                                f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, "
-                               f"merge{'' if args.std == 'none' else '+uncertainty'} (LINEAR ICRF 3x256, Gaussian weights, "
+                               f"merge{'' if args.std == 'none' else '+uncertainty'} ({args.interp.upper()} ICRF 3x256"
+                               f"{'' if args.max_code == 65535 else ', Normalize(' + str(args.max_code) + ')'}, Gaussian weights, "
                                f"sigma: {args.std}, float64 mean + float32 std out)"
                                + (", per-band statistics all_gather (RCCL) inside every step" if strong else ""),
                    "global_image": f"{h_global}x{w}x3 in {world} row band(s)", "kernel": kernel,
@@ -746,6 +755,9 @@ def main():
                          "--global-size^2 image cut into N row bands with the per-band statistics gather in every step")
     ap.add_argument("--global-size", type=int, default=8192, help="--scaling strong: rows = columns of the global image")
     ap.add_argument("--f64-moments", action="store_true", help="merge: time the float64-moment kernel (round-1 path)")
+    ap.add_argument("--max-code", type=int, default=65535, choices=[65535, 16383, 4095, 1023],
+                    help="merge: what Normalize divides the uint16 codes by (12-bit camera data: 4095)")
+    ap.add_argument("--interp", default="linear", choices=["linear", "lookup", "catmull"], help="merge: ICRF interpolation mode")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc", "nhwc_bgr"],
                     help="merge / linearize: memory order of the stack (nhwc = as decoded, nhwc_bgr = OpenCV's channel order)")
     ap.add_argument("--exposures", type=int, default=32)
