@@ -156,6 +156,146 @@ __global__ __launch_bounds__(kBlock) void linearize_kernel(const LinArgs a)
     }
 }
 
+// Planar frames, K packets of four elements per thread, the packets of one thread a whole workgroup apart: every load
+// (8 bytes per lane for uint16 codes) and every store (16 bytes per lane) of a wavefront is dense, and K loads are in
+// flight per thread.  The 8-elements-per-thread mapping of linearize_kernel writes 32 bytes per lane with two half-dense
+// store instructions; the pixel-owning RGB kernel below, whose stores are dense, ran the same C4 workload in 0.70 ms
+// against 0.84 ms (profiles/r03_layout_ingest.md) -- this kernel gives the planar layout the same access shape.
+// Per-element arithmetic is the same function call as everywhere else (bit-identical results).  q_count: a multiple of 4.
+template <typename T, int K, int INTERP, int STD, bool WRITE_STD>
+__global__ __launch_bounds__(kBlock) void linearize_planar_kernel(const LinArgs a)
+{
+    extern __shared__ __align__(16) char lds[];
+    constexpr bool kRanged = sizeof(T) != 4;
+    constexpr int kEntry = lut_entry_bytes(INTERP);
+    const int C = a.channels, L = a.n_points;
+    stage_lut<INTERP>(lds, a.lut, C, L);
+    __syncthreads();
+    const float top = (float)(L - 1);
+    const uint32_t n_packets = a.q_count / 4u;
+    uint32_t q0[K];
+    bool live[K];
+    int row_off[K][4];
+    const int skip_mod = (int)(a.tile.chan_skip % (uint32_t)C);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t pk = (blockIdx.x * (uint32_t)K + (uint32_t)k) * (uint32_t)kBlock + threadIdx.x;
+        live[k] = pk < n_packets;
+        q0[k] = a.q_begin + (live[k] ? pk : 0u) * 4u;
+        int ch = 0;
+        for (int c = 1; c < C; ++c) ch += q0[k] >= (uint32_t)c * a.tile.plane_local ? 1 : 0;
+        const uint32_t qg = q0[k] + (uint32_t)ch * a.tile.chan_skip + a.tile.base;
+        uint32_t off = q0[k] - (uint32_t)ch * a.tile.plane_local;
+        int r = C == 3 ? (int)(qg % 3u) : (int)(qg % (uint32_t)C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            row_off[k][e] = (INTERP == CT_INTERP_LOOKUP ? ch : r) * L * kEntry;
+            int inc = 1;
+            if (++off == a.tile.plane_local) {
+                off = 0;
+                ++ch;
+                inc += skip_mod;
+            }
+            r += inc;
+            r = r >= C ? r - C : r;
+        }
+    }
+    if (!live[0]) return;
+    for (uint32_t f = blockIdx.y; f < a.n_frames; f += gridDim.y) {
+        float xin[K][4];
+        LPacket<float, 4> sp[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {  // all loads first
+            if constexpr (sizeof(T) != 4) {
+                const uint64_t base = reinterpret_cast<uint64_t>(a.frames) + (uint64_t)((int64_t)f * a.image_stride * (int64_t)sizeof(T));
+                load_codes_as_float<T, 4>(base, q0[k] * (uint32_t)sizeof(T), xin[k]);
+            } else {
+                const LPacket<T, 4> pk = *reinterpret_cast<const LPacket<T, 4> *>(static_cast<const T *>(a.frames) + (int64_t)f * a.image_stride + q0[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xin[k][e] = pk.v[e];
+            }
+            if constexpr (STD == CT_STD_EXPLICIT) sp[k] = *reinterpret_cast<const LPacket<float, 4> *>(a.std_stack + (int64_t)f * a.image_stride + q0[k]);
+        }
+        LPacket<float, 4> lo[K], so[K];
+        [[maybe_unused]] bool tiny = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = sizeof(T) != 4 ? code_to_pixel(xin[k][e], a.norm) : xin[k][e];
+                float dfdx;
+                lo[k].v[e] = icrf_sample<INTERP, true, kRanged>(x, lds + row_off[k][e], top, dfdx);
+                so[k].v[e] = 0.0f;
+                if constexpr (WRITE_STD && STD != CT_STD_NONE) {
+                    float sigma = a.std_value;
+                    if constexpr (STD == CT_STD_EXPLICIT) sigma = sp[k].v[e];
+                    if constexpr (STD == CT_STD_MULTIPLIER) sigma = x * a.std_value;  // datasets/base.py:133
+                    const float ags = fabsf(dfdx * sigma);  // linearization.py:106,132: sqrt((grad * std)^2) = |grad * std| ...
+                    so[k].v[e] = ags;
+                    tiny |= ags < 1e-18f && ags != 0.0f;    // ... unless the square underflows
+                }
+            }
+        }
+        if constexpr (WRITE_STD && STD != CT_STD_NONE) {
+            if (__builtin_expect(__any(tiny), 0)) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (so[k].v[e] < 1e-18f && so[k].v[e] != 0.0f) so[k].v[e] = sqrtf(so[k].v[e] * so[k].v[e]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (!live[k]) continue;
+            const int64_t ooff = (int64_t)f * a.out_stride + q0[k];
+            store_stream(reinterpret_cast<LPacket<float, 4> *>(a.lin_out + ooff), lo[k]);
+            if constexpr (WRITE_STD) store_stream(reinterpret_cast<LPacket<float, 4> *>(a.std_out + ooff), so[k]);
+        }
+    }
+}
+
+constexpr int kLinPackets = 3;  // packets per thread of linearize_planar_kernel (12 elements, like the RGB kernel)
+
+template <typename T, int INTERP, int STD, bool WRITE_STD>
+static int lin_launch_planar(const LinArgs &a, hipStream_t s)
+{
+    if (a.q_count == 0 || a.n_frames == 0) return CT_OK;
+    const uint32_t packets = a.q_count / 4, gx = (packets + kBlock * kLinPackets - 1) / (kBlock * kLinPackets);
+    uint32_t gy = (a.n_frames + 1) / 2;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    const size_t lds = INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP);
+    if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
+    hipLaunchKernelGGL((linearize_planar_kernel<T, kLinPackets, INTERP, STD, WRITE_STD>), dim3(gx, gy), dim3(kBlock), lds, s, a);
+    return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int INTERP>
+static int lin_dispatch_planar_std(const LinArgs &a, int std_mode, bool write_std, hipStream_t s)
+{
+    if (!write_std) return lin_launch_planar<T, INTERP, CT_STD_NONE, false>(a, s);
+    switch (std_mode) {
+        case CT_STD_NONE: return lin_launch_planar<T, INTERP, CT_STD_NONE, true>(a, s);
+        case CT_STD_CONSTANT: return lin_launch_planar<T, INTERP, CT_STD_CONSTANT, true>(a, s);
+        case CT_STD_MULTIPLIER: return lin_launch_planar<T, INTERP, CT_STD_MULTIPLIER, true>(a, s);
+        case CT_STD_EXPLICIT: return lin_launch_planar<T, INTERP, CT_STD_EXPLICIT, true>(a, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
+template <typename T>
+static int lin_dispatch_planar(const LinArgs &a, int interp, int std_mode, bool write_std, hipStream_t s)
+{
+    switch (interp) {
+        case CT_INTERP_LOOKUP: return lin_dispatch_planar_std<T, CT_INTERP_LOOKUP>(a, std_mode, write_std, s);
+        case CT_INTERP_LINEAR: return lin_dispatch_planar_std<T, CT_INTERP_LINEAR>(a, std_mode, write_std, s);
+        case CT_INTERP_CATMULL: return lin_dispatch_planar_std<T, CT_INTERP_CATMULL>(a, std_mode, write_std, s);
+        case CT_INTERP_NONE: return lin_dispatch_planar_std<T, CT_INTERP_NONE>(a, std_mode, write_std, s);
+    }
+    return CT_ERR_INVALID_ARGUMENT;
+}
+
 // Interleaved RGB / BGR frames (C == 3: what OpenCV decodes to, clair_torch/common/data_io.py:125-154): a thread owns four
 // consecutive PIXELS = 12 memory elements (three typed loads of four codes each, or three 16-byte loads of float pixels),
 // so every channel plane of the planar outputs receives its four consecutive pixels as ONE 16-byte streaming store.  The
@@ -347,6 +487,17 @@ static int lin_typed(LinArgs a, uint32_t Q, int interp, int std_mode, bool write
         a.q_begin = 0;
         a.q_count = Q;  // 3 * plane_local: a multiple of 12
         return lin_dispatch_rgb<T>(a, interp, std_mode, write_std, s);
+    }
+    // planar frames with whole packets of four everywhere: the dense-access kernel (K packets per thread)
+    if (a.tile.layout == CT_LAYOUT_NCHW && Q >= 4 && aligned(a.frames, sizeof(T) * 4) && (a.image_stride % 4) == 0 &&
+        aligned(a.std_stack, 16) && aligned(a.lin_out, 16) && aligned(a.std_out, 16) && a.out_stride % 4 == 0) {
+        a.q_begin = 0;
+        a.q_count = (Q / 4) * 4;
+        rc = lin_dispatch_planar<T>(a, interp, std_mode, write_std, s);
+        if (rc != CT_OK || a.q_count == Q) return rc;
+        a.q_begin = a.q_count;
+        a.q_count = Q - a.q_begin;
+        return lin_dispatch<T, 1>(a, interp, std_mode, write_std, s);
     }
     if (q_vec) {
         a.q_begin = 0;
