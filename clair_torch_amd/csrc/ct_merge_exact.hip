@@ -8,7 +8,7 @@
 // reference by its own rounding noise: up to 2e-5 element-wise for CATMULL on uint16 data, 5e-6 for the other modes
 // (tests/test_oracle_golden.py measures it).  This kernel follows the reference instead, operation by operation:
 //
-//   pass 1 over the batch:  w_n = exp(-30 (x - 1/2)^2) (float32 ops, the exp correctly rounded), lin_n = model forward in
+//   pass 1 over the batch:  w_n = exp(-30 (x - 1/2)^2) (float32 ops, the exp rounded once from float64), lin_n = model forward in
 //                           the reference's un-fused order, y_n = lin_n / t_n (float64), W_b = sum w (float32, in the
 //                           summation order of torch.sum), S = sum w y (float64)
 //   per element:            D, m_b, W_t, frac, mean and the gradients of the scalar chain exactly as autograd's nodes run
@@ -24,8 +24,8 @@
 // (tests/test_gpu_merge.py).  Used for CATMULL with uncertainties by default and for any mode with
 // CT_MERGE_REFERENCE_ORDER.
 //
-// Cost: two passes over the batch (the second mostly from L2 / Infinity Cache), float64 divisions and a float64 exp per
-// sample: 3-5x the time of the fast kernels.  Roofline: not bandwidth -- float64 VALU.  It is a parity instrument for the
+// Cost: two passes over the batch (the second mostly from L2 / Infinity Cache), a float64 exp per sample and pass and the
+// float64 scalar chain: 3-5x the time of the fast kernels.  Roofline: not bandwidth -- float64 VALU.  It is a parity instrument for the
 // modes whose reference result is dominated by float32 cancellation, not the headline path.
 #include "ct_merge.hpp"
 
@@ -58,9 +58,32 @@ struct TorchRowSum {
     __device__ __forceinline__ float total() const { return ((a0 + a1) + a2) + a3; }
 };
 
-// exp of a float32 argument, correctly rounded (float64 exp, one rounding): torch's CPU exp (Sleef expf, 1 ULP) returns
-// the correctly rounded value for 98.9 % of arguments; the other 1.1 % are the irreducible difference to the recorded vectors.
-__device__ __forceinline__ float exp_correctly_rounded(float v) { return (float)exp((double)v); }
+// exp of a float32 argument, rounded once from a float64 value with relative error < 3e-13 (range reduction by ln 2 in two
+// parts, Taylor polynomial of degree 10 on |r| <= 0.347, one ldexp): the float32 result is the correctly rounded one for
+// all but ~2e-7 of the arguments (checked against numpy's float64 exp on 5 M arguments).  A third of the cost of the
+// library's float64 exp, which mattered: this kernel evaluates it twice per sample.  torch's CPU exp (Sleef expf, 1 ULP)
+// returns the correctly rounded value for 98.9 % of arguments; the other 1.1 % are the irreducible difference to the
+// recorded vectors.
+__device__ __forceinline__ float exp_correctly_rounded(float v)
+{
+    const double x = (double)v;
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(k, -0x1.62e42fefa38p-1, x);     // ln 2, high part (low bits cleared: k * hi is exact)
+    r = __builtin_fma(k, -0x1.ef35793c7673p-45, r);           // ln 2, low part
+    double p = 2.755731922398589e-07;                         // 1 / 10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 1.3888888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double kk = k < -1100.0 ? -1100.0 : k;              // (very negative arguments underflow to zero like exp)
+    return (float)__builtin_ldexp(p, (int)kk);
+}
 
 // Correctly rounded float32 square root.  hipcc's own expansion (__fsqrt_rn / sqrtf: v_sqrt_f32 plus a one-step fix-up)
 // was measured 1 ULP low on 17 % of the variances of the recorded fixtures on gfx950 (true root up to 0.86 ULP above the
@@ -89,6 +112,11 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
     constexpr int kEntry = lut_entry_bytes(INTERP);
     const int C = a.channels, L = a.n_points, B = a.batch;
     stage_lut<INTERP, false>(lds, a.lut, C, L);
+    // 1 / t_n in float64, once per workgroup: y_n = lin_n / t_n and G_n = (g_S w_n) / t_n are formed as products with it
+    // (at most one float64 ulp from the divisions the reference performs, i.e. invisible after the float32 casts except on
+    // ~1e-9 of the samples) -- three float64 divisions per sample were a quarter of this kernel's time
+    double *inv_t = reinterpret_cast<double *>(lds + ((INTERP == CT_INTERP_NONE ? 0 : C * L * kEntry) + 7 & ~7));
+    for (int n = threadIdx.x; n < B; n += kBlock) inv_t[n] = 1.0 / a.exposure[n];
     __syncthreads();
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
     const bool first = a.flags & CT_MERGE_FIRST_BATCH, finalize = a.flags & CT_MERGE_FINALIZE;
@@ -127,12 +155,12 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
     for (int e = 0; e < V; ++e) S[e] = 0.0;
     for (int n = 0; n < B; ++n) {
         const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)n * a.image_stride);
-        const double t = a.exposure[n];
+        const double it = inv_t[n];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float x, xm, w, lin;
             forward(pk.v[e], row[e], x, xm, w, lin);
-            const double y = (double)lin / t;                            // hdr_merge.py:103 (float32 / float64)
+            const double y = (double)lin * it;                           // hdr_merge.py:103 (float32 / float64)
             Wsum[e].add(w, n);
             S[e] = S[e] + (double)w * y;                                 // statistics.py:79
         }
@@ -171,13 +199,13 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
             const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)n * a.image_stride);
             Packet<float, V> sp;
             if constexpr (STD == CT_STD_EXPLICIT) sp = *reinterpret_cast<const Packet<float, V> *>(ssrc + (int64_t)n * a.image_stride);
-            const double t = a.exposure[n];
+            const double it = inv_t[n];
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float x, xm, w, lin;
                 forward(pk.v[e], row[e], x, xm, w, lin);
-                const double y = (double)lin / t;
-                const float g_lin = (float)((g_s[e] * (double)w) / t);    // mul backward (float64), / exposure, cast at the model output
+                const double y = (double)lin * it;
+                const float g_lin = (float)((g_s[e] * (double)w) * it);   // mul backward (float64), / exposure, cast at the model output
                 float g_x = icrf_grad_reference_order<INTERP>(x, row[e], top, g_lin);   // model nodes run before the weight nodes
                 if constexpr (kGauss) {
                     const float g_w = (float)(g_s[e] * y) + g_wb[e];      // the product's gradient arrives first, then the expanded sum's
@@ -217,7 +245,8 @@ static int exact_launch(const MergeArgs &a, hipStream_t s)
 {
     if (a.q_count == 0) return CT_OK;
     const uint32_t vecs = (a.q_count + V - 1) / V, grid = (vecs + kBlock - 1) / kBlock;
-    const size_t lds = INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP);
+    const size_t lds = ((INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP)) + 7 & ~(size_t)7) +
+                       sizeof(double) * (size_t)a.batch;
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
     hipLaunchKernelGGL((merge_reference_order_kernel<T, V, INTERP, WEIGHT, STD>), dim3(grid), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
