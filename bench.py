@@ -658,6 +658,8 @@ def run_train(args, rank, world, dev):
     n_exp, h, w = args.train_exposures, args.train_size, args.train_size
     codes, exposures = synthetic_exposure_stack(n_exp, 3, h, w, bits=16, stops_per_step=0.125, seed=1237, device=dev)
     t = torch.tensor(exposures, dtype=torch.float64)
+    if args.layout != "nchw":  # the stack as decoded: (N, H, W, C), BGR order for nhwc_bgr; the staging gathers it
+        codes = (codes.flip(1) if args.layout == "nhwc_bgr" else codes).permute(0, 2, 3, 1).contiguous()
     i, j, r = get_valid_exposure_pairs(t, 0.25)
     pairs = ops.PairList(i, j, r, n_exp, dev)
     params = [torch.nn.Parameter((torch.linspace(0, 1, 256) ** 2.5).to(dev)) for _ in range(3)]
@@ -668,7 +670,7 @@ def run_train(args, rank, world, dev):
             o.zero_grad()
         lut = torch.stack(params)
         lin, _ = linearity_loss(lut, codes, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
-                                use_unc_weight=False)
+                                use_unc_weight=False, layout=args.layout)
         lin.sum().backward()
         for o in opts:
             o.step()
@@ -686,7 +688,9 @@ def run_train(args, rank, world, dev):
             "value": round(args.steps / elapsed, 3), "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: {n_exp}-exposure {h}x{w}x3 uint16 stack, {pairs.n_pairs} pairs, relative loss"},
+            "config": {"workload": f"C3: {n_exp}-exposure {h}x{w}x3 uint16 stack"
+                                   f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, "
+                                   f"{pairs.n_pairs} pairs, relative loss"},
             "roofline": _train_roofline(pairs.n_pairs, 3 * h * w, elapsed / args.steps),
             **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_train(args.cpu_seconds)})}
 

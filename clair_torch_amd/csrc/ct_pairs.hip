@@ -84,6 +84,19 @@ __device__ __forceinline__ float load_pixel(const void *base, int64_t idx, NormC
     return to_pixel<T>(static_cast<const T *>(base)[idx], nc);
 }
 
+// Where channel plane c of pixel `pixel` (index inside the tile's plane) lives in one image, and the distance to the next
+// pixel of the same plane: planar stacks c * plane + pixel / 1, interleaved (H, W, C) stacks pixel * C + c' / C with
+// c' = c (RGB order) or C - 1 - c (BGR, what OpenCV decodes to; general_functions.py:315-335 is folded in here).
+__device__ __forceinline__ uint32_t sample_index(const PairArgs &a, int c, uint32_t pixel, uint32_t &pixel_stride)
+{
+    if (a.tile.layout == CT_LAYOUT_NCHW) {
+        pixel_stride = 1u;
+        return (uint32_t)c * a.plane_local + pixel;
+    }
+    pixel_stride = (uint32_t)a.channels;
+    return pixel * (uint32_t)a.channels + (uint32_t)(a.tile.layout == CT_LAYOUT_NHWC_BGR ? a.channels - 1 - c : c);
+}
+
 // element e of a packed raw vector as a float: one conversion straight from the packed dword (no unpacking)
 __device__ __forceinline__ float raw_code_as_float(uint32_t v, int e) { return (float)((v >> (8 * e)) & 0xffu); }  // v_cvt_f32_ubyteN
 __device__ __forceinline__ float raw_code_as_float(uint2 v, int e)
@@ -142,7 +155,9 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
     const char *row = lut_lds + (inb ? lut_row<INTERP>(qg, c, a.channels) : 0) * L * kEntry;
     // samples are walked in batches of kBatch with all of a batch's HBM loads issued before the first is used
     constexpr int kBatch = 4;
-    const T *src = static_cast<const T *>(a.stack) + ql;
+    uint32_t pstride;
+    const uint32_t qm = sample_index(a, c, pix0 + (uint32_t)px, pstride);  // == ql for planar stacks
+    const T *src = static_cast<const T *>(a.stack) + qm;
     if constexpr (sizeof(T) != 4 && INTERP == CT_INTERP_LINEAR && STD == CT_STD_NONE) {
         if (a.code_domain) {
             const uint32_t rowc = lds_row_constant((inb ? lut_row<INTERP>(qg, c, a.channels) : 0) * L * kEntry);
@@ -182,7 +197,7 @@ __device__ __forceinline__ void stage_tile(const PairArgs &a, const char *lut_ld
             const int n = nb + k * nstep;
             const bool live = inb && n < N;
             raw[k] = live ? src[(int64_t)n * a.image_stride] : T(0);
-            if constexpr (STD == CT_STD_EXPLICIT) sraw[k] = live ? a.std_stack[(int64_t)n * a.image_stride + ql] : 0.0f;
+            if constexpr (STD == CT_STD_EXPLICIT) sraw[k] = live ? a.std_stack[(int64_t)n * a.image_stride + qm] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
@@ -234,6 +249,17 @@ __device__ __forceinline__ uint8_t raw_elem(uint32_t v, int e) { return (uint8_t
 __device__ __forceinline__ uint16_t raw_elem(uint2 v, int e) { return (uint16_t)((e < 2 ? v.x : v.y) >> (16 * (e & 1))); }
 __device__ __forceinline__ float raw_elem(float4 v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
+// four strided elements gathered into the packed form the vector load would have delivered (interleaved stacks)
+__device__ __forceinline__ uint32_t pack_raw(uint8_t a, uint8_t b, uint8_t c, uint8_t d)
+{
+    return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+__device__ __forceinline__ uint2 pack_raw(uint16_t a, uint16_t b, uint16_t c, uint16_t d)
+{
+    return make_uint2((uint32_t)a | ((uint32_t)b << 16), (uint32_t)c | ((uint32_t)d << 16));
+}
+__device__ __forceinline__ float4 pack_raw(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+
 __device__ __forceinline__ int pixel_of_column(const PairArgs &a, int col)
 {
     if (!a.vec) return col;
@@ -262,6 +288,28 @@ struct VecStager {
         const int pg = (int)threadIdx.x & ((1 << gshift) - 1);
         const int n0 = (int)threadIdx.x >> gshift, nstep = block >> gshift;
         const bool inb = 4 * pg < npix;
+        if (a.tile.layout != CT_LAYOUT_NCHW) {
+            // Interleaved stack: the group's four pixels of plane c are C elements apart.  Four element loads rebuild the
+            // packed vector; the other C - 1 planes' share of the same cache lines is read by those planes' workgroups
+            // (channel-major grid: the launch streams the stack C times, out of HBM when it exceeds the caches -- the
+            // pair phase, not the staging, bounds these kernels).
+            uint32_t ps;
+            const uint32_t qm = sample_index(a, c, pix0 + 4u * (uint32_t)pg, ps);
+            const T *src = static_cast<const T *>(a.stack) + qm;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int n = n0 + k * nstep;
+                if (inb && n < a.n_images) {
+                    const T *p = src + (int64_t)n * a.image_stride;
+                    raw[k] = pack_raw(p[0], p[ps], p[2u * ps], p[3u * ps]);
+                    if constexpr (STD == CT_STD_EXPLICIT) {
+                        const float *q = a.std_stack + (int64_t)n * a.image_stride + qm;
+                        sraw[k] = make_float4(q[0], q[ps], q[2u * ps], q[3u * ps]);
+                    }
+                }
+            }
+            return;
+        }
         const uint32_t ql = (uint32_t)c * a.plane_local + pix0 + 4u * (uint32_t)pg;
         const T *src = static_cast<const T *>(a.stack) + ql;
 #pragma unroll
@@ -1004,9 +1052,11 @@ template <typename T>
 static int vec_ok(const PairArgs &a, int block, int max_passes)
 {
     const int nstep = block / (a.tp / 4);
-    const bool aligned = a.plane_local % 4 == 0 && a.image_stride % 4 == 0 &&
-                         reinterpret_cast<uintptr_t>(a.stack) % (4 * sizeof(T)) == 0 &&
-                         (a.std_stack == nullptr || reinterpret_cast<uintptr_t>(a.std_stack) % 16 == 0);
+    // interleaved stacks are gathered element by element: only the plane size matters (groups of four pixels)
+    const bool aligned = a.plane_local % 4 == 0 &&
+                         (a.tile.layout != CT_LAYOUT_NCHW ||
+                          (a.image_stride % 4 == 0 && reinterpret_cast<uintptr_t>(a.stack) % (4 * sizeof(T)) == 0 &&
+                           (a.std_stack == nullptr || reinterpret_cast<uintptr_t>(a.std_stack) % 16 == 0)));
     return aligned && (a.n_images + nstep - 1) / nstep <= max_passes ? 1 : 0;
 }
 
@@ -1219,7 +1269,7 @@ static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, con
         return CT_ERR_INVALID_ARGUMENT;
     if (g->h_global * g->width * g->channels >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
     if (g->image_stride < g->h_tile * g->width * g->channels) return CT_ERR_INVALID_ARGUMENT;
-    if (g->layout != CT_LAYOUT_NCHW) return CT_ERR_UNSUPPORTED;
+    if (g->layout < CT_LAYOUT_NCHW || g->layout > CT_LAYOUT_NHWC_BGR) return CT_ERR_INVALID_ARGUMENT;
     if (icrf->interp < CT_INTERP_LOOKUP || icrf->interp > CT_INTERP_NONE) return CT_ERR_INVALID_ARGUMENT;
     if (icrf->interp != CT_INTERP_NONE && (!icrf->lut_dev || icrf->n_points < 2)) return CT_ERR_INVALID_ARGUMENT;
     if (prm->std_mode < CT_STD_NONE || prm->std_mode > CT_STD_EXPLICIT) return CT_ERR_INVALID_ARGUMENT;
@@ -1232,7 +1282,7 @@ static int fill_common(PairArgs &a, const void *stack_dev, int32_t n_images, con
     a.tile.plane_local = (uint32_t)(g->h_tile * g->width);
     a.tile.chan_skip = (uint32_t)((g->h_global - g->h_tile) * g->width);
     a.tile.base = (uint32_t)(g->row_offset * g->width);
-    a.tile.layout = CT_LAYOUT_NCHW;
+    a.tile.layout = (uint32_t)g->layout;  // planar, or interleaved RGB / BGR (the stack AND an explicit std stack)
     a.tile.channels = (uint32_t)g->channels;
     a.plane_local = a.tile.plane_local;
     a.n_images = n_images;

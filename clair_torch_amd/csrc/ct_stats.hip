@@ -10,6 +10,10 @@
 // walked twice -- out of registers when the batch has at most 32 frames (video_stats_cached_kernel: every frame is
 // loaded and linearized exactly once, all loads in flight together), out of memory otherwise (video_stats_kernel).
 // Both form the sums in the reference's order, so they agree bit for bit.  HBM-bound.
+//
+// Interleaved (F, H, W, C) frames as OpenCV decodes them (IL instantiations): a thread still owns V consecutive MEMORY
+// elements -- the frame loads stay packets -- and only the LUT row and the position in the planar (C, H, W) state follow
+// from TileMap::planar_index; the state is touched element by element, once per batch of frames.
 #include "ct_device.hpp"
 
 namespace ct {
@@ -32,10 +36,26 @@ struct alignas(sizeof(T) * V) SPacket {
 };
 
 // Merge of the batch statistics into the running state (statistics.py:245-251), shared by both kernels.
-template <int V>
-__device__ __forceinline__ void merge_state(const StatsArgs &a, uint32_t q0, const float (&mean_b)[V], const float (&m2)[V])
+template <int V, bool IL>
+__device__ __forceinline__ void merge_state(const StatsArgs &a, uint32_t q0, const uint32_t (&pq)[V], const float (&mean_b)[V],
+                                            const float (&m2)[V])
 {
     const float WA = a.count_before, WB = (float)a.batch, W = WA + WB;
+    if constexpr (IL) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float mo = mean_b[e], vo = m2[e];
+            if (WA != 0.0f) {
+                const float ma = a.mean_state[pq[e]], va = a.m2_state[pq[e]];
+                const float delta = mean_b[e] - ma;
+                vo = va + m2[e] + (WA * WB / W) * (delta * delta);  // statistics.py:250
+                mo = ma + (WB / W) * delta;                          // statistics.py:251
+            }
+            a.mean_state[pq[e]] = mo;
+            a.m2_state[pq[e]] = vo;
+        }
+        return;
+    }
     SPacket<float, V> mo, vo;
     if (WA == 0.0f) {
 #pragma unroll
@@ -57,7 +77,7 @@ __device__ __forceinline__ void merge_state(const StatsArgs &a, uint32_t q0, con
     *reinterpret_cast<SPacket<float, V> *>(a.m2_state + q0) = vo;
 }
 
-template <typename T, int V, int INTERP>
+template <typename T, int V, int INTERP, bool IL>
 __global__ __launch_bounds__(kBlock) void video_stats_kernel(const StatsArgs a)
 {
     extern __shared__ __align__(16) char lds[];
@@ -71,11 +91,13 @@ __global__ __launch_bounds__(kBlock) void video_stats_kernel(const StatsArgs a)
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
     int row_off[V];
+    uint32_t pq[V];  // position in the planar state (== q0 + e unless the frames are interleaved)
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         int ch;
         uint32_t qg;
-        a.tile.locate(q0 + e, ch, qg);
+        pq[e] = IL ? a.tile.planar_index(q0 + e) : q0 + e;
+        a.tile.locate(pq[e], ch, qg);
         row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
     }
     const T *src = static_cast<const T *>(a.frames) + q0;
@@ -103,11 +125,11 @@ __global__ __launch_bounds__(kBlock) void video_stats_kernel(const StatsArgs a)
             m2[e] += dv * dv;
         }
     }
-    merge_state<V>(a, q0, mean_b, m2);
+    merge_state<V, IL>(a, q0, pq, mean_b, m2);
 }
 
 // Batch of at most BMAX frames: the linearized values stay in registers between the mean and the m2 pass.
-template <typename T, int V, int INTERP, int BMAX>
+template <typename T, int V, int INTERP, int BMAX, bool IL>
 __global__ __launch_bounds__(kBlock) void video_stats_cached_kernel(const StatsArgs a)
 {
     extern __shared__ __align__(16) char lds[];
@@ -121,11 +143,13 @@ __global__ __launch_bounds__(kBlock) void video_stats_cached_kernel(const StatsA
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
     int row_off[V];
+    uint32_t pq[V];  // position in the planar state (== q0 + e unless the frames are interleaved)
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         int ch;
         uint32_t qg;
-        a.tile.locate(q0 + e, ch, qg);
+        pq[e] = IL ? a.tile.planar_index(q0 + e) : q0 + e;
+        a.tile.locate(pq[e], ch, qg);
         row_off[e] = lut_row<INTERP>(qg, ch, C) * L * kEntry;
     }
     const T *src = static_cast<const T *>(a.frames) + q0;
@@ -159,23 +183,29 @@ __global__ __launch_bounds__(kBlock) void video_stats_cached_kernel(const StatsA
             }
         }
     }
-    merge_state<V>(a, q0, mean_b, m2);
+    merge_state<V, IL>(a, q0, pq, mean_b, m2);
 }
 
-template <typename T, int V, int INTERP>
-static int stats_launch(const StatsArgs &a, hipStream_t s)
+template <typename T, int V, int INTERP, bool IL>
+static int stats_launch_layout(const StatsArgs &a, hipStream_t s)
 {
     if (a.q_count == 0) return CT_OK;
     const uint32_t vecs = a.q_count / V, grid = (vecs + kBlock - 1) / kBlock;
     const size_t lds = INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP);
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
     if (a.batch <= 16)
-        hipLaunchKernelGGL((video_stats_cached_kernel<T, V, INTERP, 16>), dim3(grid), dim3(kBlock), lds, s, a);
+        hipLaunchKernelGGL((video_stats_cached_kernel<T, V, INTERP, 16, IL>), dim3(grid), dim3(kBlock), lds, s, a);
     else if (a.batch <= 32)
-        hipLaunchKernelGGL((video_stats_cached_kernel<T, V, INTERP, 32>), dim3(grid), dim3(kBlock), lds, s, a);
+        hipLaunchKernelGGL((video_stats_cached_kernel<T, V, INTERP, 32, IL>), dim3(grid), dim3(kBlock), lds, s, a);
     else
-        hipLaunchKernelGGL((video_stats_kernel<T, V, INTERP>), dim3(grid), dim3(kBlock), lds, s, a);
+        hipLaunchKernelGGL((video_stats_kernel<T, V, INTERP, IL>), dim3(grid), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
+}
+
+template <typename T, int V, int INTERP>
+static int stats_launch(const StatsArgs &a, hipStream_t s)
+{
+    return a.tile.layout == CT_LAYOUT_NCHW ? stats_launch_layout<T, V, INTERP, false>(a, s) : stats_launch_layout<T, V, INTERP, true>(a, s);
 }
 
 template <typename T, int V>
@@ -233,7 +263,7 @@ extern "C" int ct_video_stats_batch(const void *frames_dev, int32_t dtype, float
     const int64_t Qg = geom->h_global * geom->width * geom->channels, Ql = geom->h_tile * geom->width * geom->channels;
     if (Qg >= (int64_t)1 << 31) return CT_ERR_TOO_LARGE;
     if (geom->image_stride < Ql) return CT_ERR_INVALID_ARGUMENT;
-    if (geom->layout != CT_LAYOUT_NCHW) return CT_ERR_UNSUPPORTED;
+    if (geom->layout < CT_LAYOUT_NCHW || geom->layout > CT_LAYOUT_NHWC_BGR) return CT_ERR_INVALID_ARGUMENT;
     StatsArgs a{};
     a.frames = frames_dev;
     a.lut = icrf->lut_dev;
@@ -243,7 +273,7 @@ extern "C" int ct_video_stats_batch(const void *frames_dev, int32_t dtype, float
     a.tile.plane_local = (uint32_t)(geom->h_tile * geom->width);
     a.tile.chan_skip = (uint32_t)((geom->h_global - geom->h_tile) * geom->width);
     a.tile.base = (uint32_t)(geom->row_offset * geom->width);
-    a.tile.layout = CT_LAYOUT_NCHW;
+    a.tile.layout = (uint32_t)geom->layout;  // frames planar or interleaved; the state is always planar (C, H, W)
     a.tile.channels = (uint32_t)geom->channels;
     a.batch = batch;
     a.channels = geom->channels;

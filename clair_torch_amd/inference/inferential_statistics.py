@@ -31,11 +31,13 @@ def compute_video_mean_and_std(dataloader: DataLoader, device, icrf_model: Optio
     mean = m2 = None
     n_frames = 0
     for _, val_batch, _std_batch, _meta in dataloader:
-        frames, max_code = stage_images(val_batch, dev, transforms)
+        frames, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         if mean is None:
-            mean = torch.empty(tuple(frames.shape[1:]), dtype=torch.float32, device=dev)
+            f = frames.shape  # interleaved frames as decoded (CvToTorch folded into the kernel): the state is planar
+            chw = tuple(f[1:]) if layout == "nchw" else (f[3], f[1], f[2])
+            mean = torch.empty(chw, dtype=torch.float32, device=dev)
             m2 = torch.empty_like(mean)
-        ops.video_stats_batch(frames, mean, m2, n_frames, lut=lut, interp=interp, max_code=max_code)
+        ops.video_stats_batch(frames, mean, m2, n_frames, lut=lut, interp=interp, max_code=max_code, layout=layout)
         n_frames += frames.shape[0]
     if mean is None:
         raise ValueError("dataloader yielded no batches")

@@ -391,10 +391,12 @@ def pair_residual_sums(stack: torch.Tensor, pairs: PairList, *, lut: Optional[to
                        lower: float, upper: float, use_relative: bool, use_unc_weight: bool,
                        std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                        max_code: Optional[float] = None, level: int = 1, tile: Optional[TileGeometry] = None,
-                       center: Optional[torch.Tensor] = None):
-    """ct_pair_residual_fwd -> (P, C, 5) float64 sums [sum w m, sum v w m, sum (v-center)^2 w m, sum err m, sum m]."""
+                       center: Optional[torch.Tensor] = None, layout: str = "nchw"):
+    """ct_pair_residual_fwd -> (P, C, 5) float64 sums [sum w m, sum v w m, sum (v-center)^2 w m, sum err m, sum m].
+    ``layout`` "nhwc" / "nhwc_bgr": the stack (and an explicit std stack) is (N,H,W,C) as OpenCV decodes it."""
     _check_stack(stack)
-    n, c, _, _ = stack.shape
+    n = stack.shape[0]
+    c, _, _ = _chw(stack, layout)
     dev = stack.device
     if n != pairs.n_images:
         raise ValueError(f"pair list was built for {pairs.n_images} images, stack has {n}")
@@ -408,7 +410,7 @@ def pair_residual_sums(stack: torch.Tensor, pairs: PairList, *, lut: Optional[to
     if stack.dtype != torch.float32 and max_code is None:
         max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
     icrf, lut_keep = _icrf_struct(lut, interp, c)
-    geom = _geometry(stack, tile)
+    geom = _geometry(stack, tile, layout)
     prm = _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value)
     sums = torch.zeros((pairs.n_pairs, c, 5), dtype=torch.float64, device=dev)
     if center is not None:
@@ -430,12 +432,14 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
                            lower: float, upper: float, use_relative: bool, max_code: Optional[float] = None,
                            tile: Optional[TileGeometry] = None, use_unc_weight: bool = False,
                            std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
-                           smean: Optional[torch.Tensor] = None, lane_kernel: bool = True):
+                           smean: Optional[torch.Tensor] = None, lane_kernel: bool = True, layout: str = "nchw"):
     """ct_pair_residual_bwd -> (C, L) float64 LUT gradient of sum_pc coef_pc * D_pc * mean_pc (coef = dL/dmean / D).
     With ``use_unc_weight`` and uncertainties the weights depend on the LUT and ``smean`` (P,C) is required.
-    ``lane_kernel=False`` withholds the pair list's band hint, i.e. forces the generic backward kernel (tests)."""
+    ``lane_kernel=False`` withholds the pair list's band hint, i.e. forces the generic backward kernel (tests).
+    ``layout`` as in ``pair_residual_sums``."""
     _check_stack(stack)
-    n, c, _, _ = stack.shape
+    n = stack.shape[0]
+    c, _, _ = _chw(stack, layout)
     dev = stack.device
     if std is not None:
         std_mode = "explicit"
@@ -446,7 +450,7 @@ def pair_residual_lut_grad(stack: torch.Tensor, pairs: PairList, coef: torch.Ten
     if stack.dtype != torch.float32 and max_code is None:
         max_code = 255.0 if stack.dtype == torch.uint8 else 65535.0
     icrf, lut_keep = _icrf_struct(lut, interp, c)
-    geom = _geometry(stack, tile)
+    geom = _geometry(stack, tile, layout)
     prm = _pair_params(lower, upper, use_relative, use_unc_weight, std_mode, std_value,
                        pair_band=pairs.band if lane_kernel else 0)
     if std_mode != "none":
@@ -591,10 +595,12 @@ def dark_field_blur(stack: torch.Tensor, dark: torch.Tensor, dark_std: Optional[
 # ---- streaming video statistics -----------------------------------------------------------------------------------
 def video_stats_batch(frames: torch.Tensor, mean_state: torch.Tensor, m2_state: torch.Tensor, frames_before: int, *,
                       lut: Optional[torch.Tensor] = None, interp: Optional[str] = None,
-                      max_code: Optional[float] = None, tile: Optional[TileGeometry] = None):
-    """ct_video_stats_batch: merge one batch of frames into the running (mean, m2) float32 state in place."""
+                      max_code: Optional[float] = None, tile: Optional[TileGeometry] = None, layout: str = "nchw"):
+    """ct_video_stats_batch: merge one batch of frames into the running (mean, m2) float32 state in place.
+    ``layout`` "nhwc" / "nhwc_bgr": frames are (F,H,W,C) as OpenCV decodes them; the state stays planar (C,H,W)."""
     _check_stack(frames, "frames")
-    b, c, h, w = frames.shape
+    b = frames.shape[0]
+    c, h, w = _chw(frames, layout)
     dev = frames.device
     frames = frames.contiguous()
     if frames.dtype != torch.float32 and max_code is None:
@@ -604,7 +610,7 @@ def video_stats_batch(frames: torch.Tensor, mean_state: torch.Tensor, m2_state: 
         if t.dtype != torch.float32 or tuple(t.shape) != (c, h, w) or not t.is_contiguous():
             raise ValueError(f"{name} must be a contiguous float32 (C,H,W) tensor")
     icrf, lut_keep = _icrf_struct(lut, interp, c)
-    geom = _geometry(frames, tile)
+    geom = _geometry(frames, tile, layout)
     with torch.cuda.device(dev):
         rc = nv.load().ct_video_stats_batch(_ptr(frames), _DTYPE[frames.dtype], float(max_code or 1.0), b,
                                             ctypes.byref(geom), ctypes.byref(icrf), float(frames_before),

@@ -65,8 +65,10 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
     for epoch in range(epochs):
         running_loss = torch.zeros(channels, device=dev, dtype=torch.float64)
         for _, val_batch, std_batch, meta_batch in dataloader:
-            images, max_code = stage_images(val_batch, dev, transforms)
+            images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
             std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
+            if std is not None and layout != "nchw":  # explicit uncertainty images are planar
+                images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
             if images.shape[0] < 2:
                 print("Skipped batch due to single image.")
                 continue
@@ -84,7 +86,8 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
                                          lower=lower_valid_threshold, upper=upper_valid_threshold,
                                          use_relative=use_relative_linearity_loss,
                                          use_unc_weight=use_uncertainty_weighting, std=std, std_mode=std_mode,
-                                         std_value=std_value, max_code=max_code, tile=tile, group=group)
+                                         std_value=std_value, max_code=max_code, tile=tile, group=group,
+                                         layout=layout)
             loss = (lin_loss + alpha * compute_monotonicity_penalty(icrf_curve, per_channel=True)
                     + beta * compute_range_penalty(icrf_curve, per_channel=True)
                     + gamma * compute_endpoint_penalty(icrf_curve, per_channel=True)

@@ -72,19 +72,21 @@ class _LinearityTerm(torch.autograd.Function):
         grad = ops.pair_residual_lut_grad(ctx.stack, ctx.pairs, coef, lut=lut, interp=kw["interp"], lower=kw["lower"],
                                           upper=kw["upper"], use_relative=kw["use_relative"], max_code=kw["max_code"],
                                           tile=kw["tile"], use_unc_weight=kw["use_unc_weight"], std=kw["std"],
-                                          std_mode=kw["std_mode"], std_value=kw["std_value"], smean=spatial)
+                                          std_mode=kw["std_mode"], std_value=kw["std_value"], smean=spatial,
+                                          layout=kw["layout"])
         _all_reduce_sum(grad, ctx.group)
         return grad.to(lut.dtype), None, None, None, None
 
 
 def linearity_loss(lut: torch.Tensor, stack: torch.Tensor, pairs: ops.PairList, *, interp: str, lower: float,
                    upper: float, use_relative: bool, use_unc_weight: bool, std=None, std_mode="none", std_value=0.0,
-                   max_code=None, tile=None, group=None):
-    """Differentiable (w.r.t. ``lut``) per-channel linearity loss and the (P,C) spatial means."""
+                   max_code=None, tile=None, group=None, layout="nchw"):
+    """Differentiable (w.r.t. ``lut``) per-channel linearity loss and the (P,C) spatial means.  ``layout`` "nhwc" /
+    "nhwc_bgr": ``stack`` is (N,H,W,C) as decoded (cv_to_torch, general_functions.py:315-335, folded into the staging)."""
     if not (use_unc_weight and (std is not None or std_mode != "none")):
         std, std_mode, std_value = None, "none", 0.0  # uncertainties only enter through the weights (losses.py:93-100)
     kw = dict(interp=interp, lower=lower, upper=upper, use_relative=use_relative, use_unc_weight=use_unc_weight,
-              std=std, std_mode=std_mode, std_value=std_value, max_code=max_code, tile=tile)
+              std=std, std_mode=std_mode, std_value=std_value, max_code=max_code, tile=tile, layout=layout)
     return _LinearityTerm.apply(lut, stack, pairs, kw, group)
 
 
@@ -101,8 +103,10 @@ def measure_linearity(dataloader: DataLoader, device, use_uncertainty_weighting:
     dev = resolve_device(device)
     transforms = normalise_transform_list(gpu_transforms)
     for _, val_batch, std_batch, meta_batch in dataloader:
-        images, max_code = stage_images(val_batch, dev, transforms)
+        images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
+        if std is not None and layout != "nchw":  # explicit uncertainty images are planar
+            images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
         exposures = meta_batch["exposure_time"].to(torch.float64)
         i_idx, j_idx, ratio = get_valid_exposure_pairs(exposures, 0.2)
         pairs = ops.PairList(i_idx, j_idx, ratio, images.shape[0], dev)
@@ -111,7 +115,7 @@ def measure_linearity(dataloader: DataLoader, device, use_uncertainty_weighting:
             lut, interp = icrf_model.icrf.detach().to(dev), icrf_model.interp_name
         kw = dict(lut=lut, interp=interp, lower=1 / 255, upper=254 / 255, use_relative=use_relative_linearity_loss,
                   use_unc_weight=use_uncertainty_weighting, std=std, std_mode=std_mode, std_value=std_value,
-                  max_code=max_code, level=1, tile=tile)
+                  max_code=max_code, level=1, tile=tile, layout=layout)
         sums = _all_reduce_sum(ops.pair_residual_sums(images, pairs, **kw), group)
         centered = _all_reduce_sum(ops.pair_residual_sums(images, pairs, center=spatial_mean(sums), **kw), group)
         mean, sd, err = spatial_statistics(sums, centered, std_mode != "none")

@@ -42,7 +42,8 @@ def _install_stand_ins(whole_x):
     from oracle import eager_torch as oe
 
     def fake_sums(stack, pairs, *, lut, interp, lower, upper, use_relative, use_unc_weight, std=None, std_mode="none",
-                  std_value=0.0, max_code=None, level=1, tile=None, center=None):
+                  std_value=0.0, max_code=None, level=1, tile=None, center=None, layout="nchw"):
+        assert layout == "nchw"
         geom = None if tile is None else (tile.h_global, tile.row_offset)
         x = stack.numpy()
         lin = oc.icrf_forward(x, lut.detach().numpy(), interp, tile=geom)
