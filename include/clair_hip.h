@@ -74,7 +74,9 @@ extern "C" {
 /* Memory layout of one image of a stack.  Outputs and state are always planar (C, H, W) like the reference's tensors.
  * NHWC = the interleaved layout OpenCV decodes to (clair_torch/common/data_io.py:125-154); NHWC_BGR additionally
  * reverses the channel order on the fly, i.e. folds cv_to_torch (clair_torch/common/general_functions.py:315-335)
- * into the load.  Supported by ct_hdr_merge_batch and ct_linearize_std; the other entry points take NCHW only. */
+ * into the load.  Supported by ct_hdr_merge_batch(es), ct_linearize_std, ct_pair_residual_fwd / _bwd and
+ * ct_video_stats_batch (an explicit std stack is then interleaved likewise); flat field, dark field and band
+ * statistics work on planar data. */
 #define CT_LAYOUT_NCHW 0
 #define CT_LAYOUT_NHWC 1
 #define CT_LAYOUT_NHWC_BGR 2
