@@ -27,6 +27,7 @@
 // Cost: two passes over the batch (the second mostly from L2 / Infinity Cache), a float64 exp per sample and pass and the
 // float64 scalar chain: 3-5x the time of the fast kernels.  Roofline: not bandwidth -- float64 VALU.  It is a parity instrument for the
 // modes whose reference result is dominated by float32 cancellation, not the headline path.
+#include <cstdlib>
 #include "ct_merge.hpp"
 
 namespace ct {
@@ -103,7 +104,13 @@ __device__ __forceinline__ float sqrt_correctly_rounded(float v)
     return s;
 }
 
-template <typename T, int V, int INTERP, int WEIGHT, int STD>
+// CACHE (small batches -- the reference's scripts stream batches of 4): pass 1 leaves every sample's weight (CACHE >= 1) and
+// linearized value (CACHE == 2) in LDS, wc[n][e][thread] / lc[n][e][thread], so that pass 2 neither exponentiates nor
+// interpolates a second time -- identical values by construction (the same float32 results, read back).  4 B (8 B) of LDS
+// per sample: batches of up to 8 (4) exposures at four workgroups per CU.  (One element per thread would fit batches of 32,
+// and was measured slower than not caching at all: 5.4 against 3.9 ms on C2 LOOKUP -- the per-exposure overhead of the
+// loop is then paid per sample.)
+template <typename T, int V, int INTERP, int WEIGHT, int STD, int CACHE = 0>
 __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const MergeArgs a)
 {
     extern __shared__ __align__(16) char lds[];
@@ -117,6 +124,8 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
     // ~1e-9 of the samples) -- three float64 divisions per sample were a quarter of this kernel's time
     double *inv_t = reinterpret_cast<double *>(lds + ((INTERP == CT_INTERP_NONE ? 0 : C * L * kEntry) + 7 & ~7));
     for (int n = threadIdx.x; n < B; n += kBlock) inv_t[n] = 1.0 / a.exposure[n];
+    [[maybe_unused]] float *wc = reinterpret_cast<float *>(inv_t + B) + threadIdx.x;   // + (n * V + e) * kBlock: conflict-free
+    [[maybe_unused]] float *lc = wc + (size_t)B * V * kBlock;
     __syncthreads();
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
     const bool first = a.flags & CT_MERGE_FIRST_BATCH, finalize = a.flags & CT_MERGE_FINALIZE;
@@ -160,6 +169,8 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
         for (int e = 0; e < V; ++e) {
             float x, xm, w, lin;
             forward(pk.v[e], row[e], x, xm, w, lin);
+            if constexpr (CACHE >= 1) wc[(n * V + e) * kBlock] = w;
+            if constexpr (CACHE == 2) lc[(n * V + e) * kBlock] = lin;
             const double y = (double)lin * it;                           // hdr_merge.py:103 (float32 / float64)
             Wsum[e].add(w, n);
             S[e] = S[e] + (double)w * y;                                 // statistics.py:79
@@ -203,7 +214,19 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float x, xm, w, lin;
-                forward(pk.v[e], row[e], x, xm, w, lin);
+                if constexpr (CACHE == 0) {
+                    forward(pk.v[e], row[e], x, xm, w, lin);
+                } else {
+                    x = to_pixel<T>(pk.v[e], a.norm);
+                    xm = x - 0.5f;
+                    w = wc[(n * V + e) * kBlock];
+                    if constexpr (CACHE == 2) {
+                        lin = lc[(n * V + e) * kBlock];
+                    } else {
+                        float unused;
+                        lin = icrf_sample<INTERP, true, false>(x, row[e], top, unused);
+                    }
+                }
                 const double y = (double)lin * it;
                 const float g_lin = (float)((g_s[e] * (double)w) * it);   // mul backward (float64), / exposure, cast at the model output
                 float g_x = icrf_grad_reference_order<INTERP>(x, row[e], top, g_lin);   // model nodes run before the weight nodes
@@ -240,21 +263,57 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
     }
 }
 
-template <typename T, int V, int INTERP, int WEIGHT, int STD>
+static size_t exact_fixed_lds(const MergeArgs &a, int interp)
+{
+    return ((interp == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(interp)) + 7 & ~(size_t)7) +
+           sizeof(double) * (size_t)a.batch;
+}
+
+// Values kept per sample between the passes: 2 (weight and linearized value) while a workgroup's cache stays within
+// kCacheBudget -- four workgroups per CU --, 1 (the weight: the float64 exp is the expensive half) up to twice that, else 0.
+constexpr size_t kCacheBudget = 37 * 1024;
+static int exact_cache_level(const MergeArgs &a, int interp, int weight_mode, int std_mode, int v)
+{
+    if (std_mode == CT_STD_NONE) return 0;  // no second pass
+    static const bool disabled = getenv("CT_EXACT_NO_CACHE") != nullptr;  // diagnostics: time the two-pass form alone
+    if (disabled) return 0;
+    const size_t per_level = (size_t)a.batch * v * kBlock * sizeof(float);
+    if (exact_fixed_lds(a, interp) + 2 * per_level <= kCacheBudget) return 2;
+    // the weight alone is only worth keeping when it is an exp
+    if (weight_mode == CT_WEIGHT_GAUSS && exact_fixed_lds(a, interp) + per_level <= kCacheBudget) return 1;
+    return 0;
+}
+
+template <typename T, int V, int INTERP, int WEIGHT, int STD, int CACHE = 0>
 static int exact_launch(const MergeArgs &a, hipStream_t s)
 {
     if (a.q_count == 0) return CT_OK;
     const uint32_t vecs = (a.q_count + V - 1) / V, grid = (vecs + kBlock - 1) / kBlock;
-    const size_t lds = ((INTERP == CT_INTERP_NONE ? 0 : (size_t)a.channels * a.n_points * lut_entry_bytes(INTERP)) + 7 & ~(size_t)7) +
-                       sizeof(double) * (size_t)a.batch;
+    const size_t lds = exact_fixed_lds(a, INTERP) + (size_t)CACHE * a.batch * V * kBlock * sizeof(float);
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
-    hipLaunchKernelGGL((merge_reference_order_kernel<T, V, INTERP, WEIGHT, STD>), dim3(grid), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((merge_reference_order_kernel<T, V, INTERP, WEIGHT, STD, CACHE>), dim3(grid), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
 template <typename T, int V, int INTERP, int WEIGHT>
 static int exact_std(const MergeArgs &a, int std_mode, hipStream_t s)
 {
+    if constexpr (V == 4) {  // the cached variants (packets only; ragged tails are a handful of elements)
+        const int level = exact_cache_level(a, INTERP, WEIGHT, std_mode, V);
+        if (level == 2) {
+            switch (std_mode) {
+                case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, 2>(a, s);
+                case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, 2>(a, s);
+                case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, 2>(a, s);
+            }
+        } else if (level == 1) {
+            switch (std_mode) {
+                case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, 1>(a, s);
+                case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, 1>(a, s);
+                case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, 1>(a, s);
+            }
+        }
+    }
     switch (std_mode) {
         case CT_STD_NONE: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, s);
         case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, s);

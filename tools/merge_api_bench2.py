@@ -11,10 +11,11 @@ from clair_torch_amd.training.losses import gaussian_value_weights
 dev = torch.device("cuda:0")
 codes, exposures = synthetic_exposure_stack(32, 3, 4096, 4096, bits=16, stops_per_step=0.25, seed=1236, device=dev)
 lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)])
-model = ICRFModelDirect(icrf=lut, interpolation_mode=InterpMode.LINEAR).to(dev)
+mode = (sys.argv[1] if len(sys.argv) > 1 else "linear").upper()   # linear | lookup | catmull
+model = ICRFModelDirect(icrf=lut, interpolation_mode=InterpMode[mode]).to(dev)
 ds = StackDataset(codes, exposures, missing_std_mode=MissingStdMode.MULTIPLIER, missing_std_value=0.05, materialize_std=False)
 tf = [CastTo("float32"), Normalize(max_val=65535, min_val=0)]
-out = {}
+out = {"interp": mode.lower()}
 for bs in (32, 8, 4):
     loader = DataLoader(ds, batch_size=bs, shuffle=False, collate_fn=custom_collate)
     for _ in range(3):
