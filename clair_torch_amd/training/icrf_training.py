@@ -62,6 +62,48 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
     icrf_model.plot_icrf()
     pair_cache = {}
 
+    # The reference reads the epoch's average loss on the host at the end of every epoch (icrf_training.py:161) and does
+    # its bookkeeping there: early stopping, schedulers, the LR messages, the plot.  A blocking read leaves the GPU idle
+    # from the end of the epoch's last kernel until the host has come back round to the next forward launch.  Here the
+    # read is a non-blocking copy plus an event, and the bookkeeping of epoch e is SETTLED inside epoch e + 1, after that
+    # epoch's forward and backward have been queued and before its first optimizer step -- the only point from which a
+    # scheduler's new learning rate or an early stop can matter.  Same updates, same messages, same returned model: when
+    # early stopping triggers, the extra forward / backward has touched nothing but the .grad buffers.
+    pending = None
+    host_loss = torch.empty(channels, dtype=torch.float64).pin_memory()
+
+    def settle(entry) -> bool:
+        """Bookkeeping of a finished epoch (icrf_training.py:161-186); True when early stopping triggers."""
+        epoch, event = entry
+        event.synchronize()
+        avg_loss = host_loss.numpy().copy()
+        if verbose:
+            print(f"Epoch {epoch + 1} Loss: {avg_loss}")
+        avg = avg_loss.reshape(-1)
+        for c in range(channels):
+            value = avg[c] if avg.size > 1 else avg[0]
+            if value < best_losses[c]:
+                best_losses[c] = value
+                epochs_without_improvement[c] = 0
+            else:
+                epochs_without_improvement[c] += 1
+        if all(epochs_without_improvement[c] >= patience for c in range(channels)):
+            if verbose:
+                print(f"Early stopping triggered for all channels (patience = {patience} epochs).")
+            return True
+        for c, scheduler in enumerate(schedulers):
+            if scheduler is not None:
+                scheduler.step(avg[c] if avg.size > 1 else avg[0])
+        for i, optimizer in enumerate(optimizers):
+            current_lr = optimizer.param_groups[0]["lr"]
+            if current_lr != previous_lrs[i] and verbose:
+                print(f"Optimizer {i} learning rate changed to: {current_lr}")
+            previous_lrs[i] = current_lr
+        if (epoch + 1) % 5 == 0:
+            icrf_model.plot_icrf()
+        return False
+
+    stopped = False
     for epoch in range(epochs):
         running_loss = torch.zeros(channels, device=dev, dtype=torch.float64)
         for _, val_batch, std_batch, meta_batch in dataloader:
@@ -104,34 +146,24 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
                     # of the sum: one ct_pair_residual_bwd launch instead of three whole-stack launches with two thirds
                     # of their coefficients zero.
                     loss[:len(optimizers)].sum().backward()
+            if pending is not None:  # the previous epoch's bookkeeping, while this epoch's kernels run
+                stopped, pending = settle(pending), None
+                if stopped:
+                    break
             for optimizer in optimizers:
                 optimizer.step()
             icrf_model.update_icrf()
             running_loss += loss.detach()
-
-        avg_loss = (running_loss / len(dataloader)).cpu().numpy()
-        if verbose:
-            print(f"Epoch {epoch + 1} Loss: {avg_loss}")
-        avg = avg_loss.reshape(-1)
-        for c in range(channels):
-            value = avg[c] if avg.size > 1 else avg[0]
-            if value < best_losses[c]:
-                best_losses[c] = value
-                epochs_without_improvement[c] = 0
-            else:
-                epochs_without_improvement[c] += 1
-        if all(epochs_without_improvement[c] >= patience for c in range(channels)):
-            if verbose:
-                print(f"Early stopping triggered for all channels (patience = {patience} epochs).")
+        if stopped:
             break
-        for c, scheduler in enumerate(schedulers):
-            if scheduler is not None:
-                scheduler.step(avg[c] if avg.size > 1 else avg[0])
-        for i, optimizer in enumerate(optimizers):
-            current_lr = optimizer.param_groups[0]["lr"]
-            if current_lr != previous_lrs[i] and verbose:
-                print(f"Optimizer {i} learning rate changed to: {current_lr}")
-            previous_lrs[i] = current_lr
-        if (epoch + 1) % 5 == 0:
-            icrf_model.plot_icrf()
+        if pending is not None:  # an epoch whose batches were all skipped never reached the point above
+            stopped, pending = settle(pending), None
+            if stopped:
+                break
+        host_loss.copy_(running_loss / len(dataloader), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        pending = (epoch, done)
+    if pending is not None and not stopped:
+        settle(pending)
     return icrf_model
