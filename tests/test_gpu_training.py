@@ -332,6 +332,90 @@ def test_train_icrf_matches_reference_run(dev, sname):
         ["_x_axis_datapoints", "_icrf", "direct_params.0", "direct_params.1", "direct_params.2"])
 
 
+def test_train_icrf_deferred_bookkeeping_equals_the_blocking_loop(dev, capsys):
+    """train_icrf settles an epoch's bookkeeping (loss read, early stopping, schedulers, messages) inside the NEXT epoch, behind
+    that epoch's queued forward / backward.  Against a loop written in the reference's blocking order
+    (icrf_training.py:96-186: read the loss, count patience, step the schedulers, then start the next epoch) it must give
+    the same curve, stop at the same epoch and print the same messages -- with a scheduler that halves the rate every
+    time the loss fails to improve and a patience that triggers early stopping."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.enums import InterpMode
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    from clair_torch_amd.datasets import StackDataset, custom_collate
+    from clair_torch_amd.models import ICRFModelDirect
+    from clair_torch_amd.training import linearity_loss, train_icrf
+    from clair_torch_amd.training.losses import (compute_endpoint_penalty, compute_monotonicity_penalty,
+                                                 compute_range_penalty, compute_smoothness_penalty)
+    from oracle import ct_oracle as oc
+    g = golden("training")
+    x = torch.from_numpy(oc.normalize_codes(g["train_codes"]))
+    t = g["train_exposures"].tolist()
+    n = x.shape[0]
+    epochs, patience, lr = 40, 3, 0.02  # a rate at which the loss soon stops improving from epoch to epoch
+
+    def make():
+        model = ICRFModelDirect(n_points=64, channels=3, interpolation_mode=InterpMode.LINEAR, initial_power=2.5).to(dev)
+        opts = [torch.optim.Adam(model.channel_params(c), lr=lr) for c in range(3)]
+        scheds = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode="min", factor=0.5, patience=0) for o in opts]
+        return model, opts, scheds
+
+    model, opts, scheds = make()
+    loader = DataLoader(StackDataset(x, t), batch_size=n, shuffle=False, collate_fn=custom_collate)
+    train_icrf(loader, n, "cuda", model, optimizers=opts, schedulers=scheds, epochs=epochs, patience=patience, alpha=10.0,
+               exposure_ratio_threshold=0.25, use_uncertainty_weighting=False, verbose=True)
+    printed = [l for l in capsys.readouterr().out.splitlines() if l.startswith(("Epoch", "Early", "Optimizer"))]
+
+    # the reference's order, blocking
+    ref, r_opts, r_scheds = make()
+    ref.train()
+    images = x.to(dev)
+    i, j, r = get_valid_exposure_pairs(torch.tensor(t, dtype=torch.float64), 0.25)
+    pairs = ops.PairList(i, j, r, n, dev)
+    best, stale, lrs, lines = [float("inf")] * 3, [0] * 3, [lr] * 3, []
+    for epoch in range(epochs):
+        for o in r_opts:
+            o.zero_grad()
+        curve = ref.icrf
+        lin, _ = linearity_loss(curve, images, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
+                                use_unc_weight=False)
+        loss = (lin + 10.0 * compute_monotonicity_penalty(curve, per_channel=True) + compute_range_penalty(curve, per_channel=True)
+                + compute_endpoint_penalty(curve, per_channel=True) + compute_smoothness_penalty(curve, per_channel=True))
+        if loss.requires_grad:
+            loss.sum().backward()
+        for o in r_opts:
+            o.step()
+        ref.update_icrf()
+        avg = loss.detach().cpu().numpy()
+        lines.append(f"Epoch {epoch + 1} Loss: {avg}")
+        for c in range(3):
+            if avg[c] < best[c]:
+                best[c], stale[c] = avg[c], 0
+            else:
+                stale[c] += 1
+        if all(s >= patience for s in stale):
+            lines.append(f"Early stopping triggered for all channels (patience = {patience} epochs).")
+            break
+        for c, sch in enumerate(r_scheds):
+            sch.step(avg[c])
+        for k, o in enumerate(r_opts):
+            cur = o.param_groups[0]["lr"]
+            if cur != lrs[k]:
+                lines.append(f"Optimizer {k} learning rate changed to: {cur}")
+            lrs[k] = cur
+    assert any(l.startswith("Early") for l in lines) and any(l.startswith("Optimizer") for l in lines), "the recipe must exercise both"
+    assert len(printed) == len(lines)
+    for a, b in zip(printed, lines):
+        if a.startswith("Epoch"):  # the loss values agree to the float64 atomics' order
+            va = np.array(a.split("Loss:")[1].strip(" []").split(), dtype=np.float64)
+            vb = np.array(b.split("Loss:")[1].strip(" []").split(), dtype=np.float64)
+            assert a.split("Loss:")[0] == b.split("Loss:")[0] and np.allclose(va, vb, rtol=1e-6, atol=0)
+        else:
+            assert a == b
+    assert_parity(model.icrf.detach().cpu().numpy(), ref.icrf.detach().cpu().numpy(), rtol=1e-8, norm_tol=1e-9, what="curve")
+    for o, q in zip(opts, r_opts):
+        assert o.param_groups[0]["lr"] == q.param_groups[0]["lr"]
+
+
 def test_train_icrf_argument_errors(dev):
     from clair_torch_amd.datasets import StackDataset, custom_collate
     from clair_torch_amd.models import ICRFModelDirect
