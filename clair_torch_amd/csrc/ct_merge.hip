@@ -1000,8 +1000,11 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             for (int e = 0; e < V; ++e) {
                 const float Wb = kGauss ? W[e] : (float)Bb;
                 const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
-                float r = __builtin_amdgcn_rcpf(Df);
-                r = r * __builtin_fmaf(-Df, r, 2.0f);
+                // v_rcp_f32 (1 ulp) as it comes: the quotient q is corrected against D below, and a last-bit error of
+                // beta = frac / D or of frac moves the variance / the mean update by 1e-7 of themselves.  (Newton steps on
+                // both reciprocals and the term-by-term quadratic form cost 8 of this epilogue's ~45 instructions, and
+                // with several batches per launch the epilogue runs once per batch and element.)
+                const float r = __builtin_amdgcn_rcpf(Df);
                 const float num = __builtin_fmaf(-p[e], 1e-6f, Swy[e]);  // sum w y - p (W + 1e-6)
                 float q = num * r;
                 q = __builtin_fmaf(__builtin_fmaf(-q, Df, num), r, q);  // m_b - p
@@ -1011,10 +1014,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     mean_o[e] = (double)p[e] + (double)q;
                 } else {
                     Wt = WA[e] + Wb;
-                    // 1 / W_t by v_rcp_f32 + one Newton step (<= 1 ulp) instead of two IEEE divisions (~20 instructions):
-                    // with several batches per launch this epilogue runs once per batch and element (statistics.py:105)
-                    float rw = __builtin_amdgcn_rcpf(Wt);
-                    rw = rw * __builtin_fmaf(-Wt, rw, 2.0f);
+                    const float rw = __builtin_amdgcn_rcpf(Wt);  // statistics.py:105, division-free
                     frac = WA[e] == 0.0f ? 1.0f : Wb * rw;  // (a fresh merge inside a MULTI launch: W_A = 0, W_B / W_B = 1 exactly)
                     const double diff = ((double)p[e] - meanA[e]) + (double)q;  // m_b - mean_A
                     mean_o[e] = __builtin_fma((double)frac, diff, meanA[e]);
@@ -1026,11 +1026,12 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 if constexpr (kHasStd) {
                     const float beta = frac * r;
                     const float kap = __builtin_fmaf(-beta, q, gam);
-                    const float t1 = beta * beta * Scc[e];
-                    const float t2 = 2.0f * beta * kap * Sac[e];
-                    const float t3 = kap * kap * Saa[e];
-                    const float upd = (t1 + t2) + t3;
-                    if constexpr (kGauss) bad[e] = (t1 + fabsf(t2)) + t3 > kPivotCondLimit * upd;
+                    // beta^2 Scc + 2 beta kappa Sac + kappa^2 Saa: the two squares first (S >= 0), then the cross term.
+                    // Cancellation test: t1 + |t2| + t3 > kPivotCondLimit * upd  <=>  t2 < 0 and upd < S * 2 / (limit + 1)
+                    const float bk = beta * kap;
+                    const float S = __builtin_fmaf(kap * kap, Saa[e], (beta * beta) * Scc[e]);
+                    const float upd = __builtin_fmaf(bk + bk, Sac[e], S);
+                    if constexpr (kGauss) bad[e] = upd * (0.5f * (kPivotCondLimit + 1.0f)) < S;
                     var += fmaxf(upd, 0.0f) * sv2;
                 }
                 var_o[e] = var;
