@@ -31,14 +31,14 @@ def stage_images(val_batch: torch.Tensor, device: torch.device, transforms: list
     CastTo(float32)+Normalize(max, 0) pair the kernels ingest directly, else float32 pixels and None.
     With ``want_layout`` a third value is returned: "nhwc_bgr" when the list additionally starts with CvToTorch
     on raw (B,H,W,3) frames (the kernel then reads the interleaved BGR frames as they are), else "nchw"."""
-    images = val_batch.to(device=device, non_blocking=True)
+    images = val_batch.to(device=device, non_blocking=True)  # the ONE host-to-device copy of the batch (a plain DMA when pinned)
     if want_layout:
         layout, rest = fusable_layout(images, transforms)
         if layout != "nchw":
             max_code = fusable_code_normalisation(images, rest)
             if max_code is not None:
                 return images, max_code, layout
-        out = stage_images(val_batch, device, transforms)
+        out = stage_images(images, device, transforms)  # already on the device: .to() is then the identity
         return out[0], out[1], "nchw"
     max_code = fusable_code_normalisation(images, transforms)
     if max_code is not None:

@@ -78,7 +78,7 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
         images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
         if (std is not None or dark is not None) and layout != "nchw":  # explicit std / dark images are planar
-            images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
+            images, max_code, layout = stage_images(images, dev, transforms) + ("nchw",)
         if dark is not None:
             xb, sig = dark.apply(index_batch, images, max_code, std, std_mode, std_value, tile, group)
             if xb is not None:  # the blurred batch replaces the images; its uncertainty carries both variance terms

@@ -80,7 +80,7 @@ def _frame_by_frame(first, items, dataloader, dev, transforms, lut, interp, flat
         images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
         if (std is not None or dark is not None) and layout != "nchw":  # explicit std / dark images are planar
-            images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
+            images, max_code, layout = stage_images(images, dev, transforms) + ("nchw",)
         if dark is not None:
             lin, lin_std = dark.linearize(index_batch, images, max_code, std, std_mode, std_value, lut, interp)
         else:

@@ -110,7 +110,7 @@ def train_icrf(dataloader: DataLoader, batch_size: int, device, icrf_model: ICRF
             images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
             std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
             if std is not None and layout != "nchw":  # explicit uncertainty images are planar
-                images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
+                images, max_code, layout = stage_images(images, dev, transforms) + ("nchw",)
             if images.shape[0] < 2:
                 print("Skipped batch due to single image.")
                 continue

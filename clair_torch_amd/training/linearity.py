@@ -106,7 +106,7 @@ def measure_linearity(dataloader: DataLoader, device, use_uncertainty_weighting:
         images, max_code, layout = stage_images(val_batch, dev, transforms, want_layout=True)
         std, std_mode, std_value = std_arguments(std_batch, dataloader.dataset, dev)
         if std is not None and layout != "nchw":  # explicit uncertainty images are planar
-            images, max_code, layout = stage_images(val_batch, dev, transforms) + ("nchw",)
+            images, max_code, layout = stage_images(images, dev, transforms) + ("nchw",)
         exposures = meta_batch["exposure_time"].to(torch.float64)
         i_idx, j_idx, ratio = get_valid_exposure_pairs(exposures, 0.2)
         pairs = ops.PairList(i_idx, j_idx, ratio, images.shape[0], dev)
