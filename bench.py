@@ -658,6 +658,10 @@ def run_train(args, rank, world, dev):
     n_exp, h, w = args.train_exposures, args.train_size, args.train_size
     codes, exposures = synthetic_exposure_stack(n_exp, 3, h, w, bits=16, stops_per_step=0.125, seed=1237, device=dev)
     t = torch.tensor(exposures, dtype=torch.float64)
+    max_code = float(args.max_code)
+    if args.max_code != 65535:  # 10- / 12- / 14-bit camera data held in uint16, normalised by its own maximum
+        shift = {16383: 2, 4095: 4, 1023: 6}[args.max_code]
+        codes = (codes.to(torch.int32) >> shift).to(torch.uint16)
     if args.layout != "nchw":  # the stack as decoded: (N, H, W, C), BGR order for nhwc_bgr; the staging gathers it
         codes = (codes.flip(1) if args.layout == "nhwc_bgr" else codes).permute(0, 2, 3, 1).contiguous()
     i, j, r = get_valid_exposure_pairs(t, 0.25)
@@ -670,7 +674,7 @@ def run_train(args, rank, world, dev):
             o.zero_grad()
         lut = torch.stack(params)
         lin, _ = linearity_loss(lut, codes, pairs, interp="linear", lower=1 / 255, upper=254 / 255, use_relative=True,
-                                use_unc_weight=False, layout=args.layout)
+                                use_unc_weight=False, layout=args.layout, max_code=max_code)
         lin.sum().backward()
         for o in opts:
             o.step()
@@ -689,7 +693,8 @@ def run_train(args, rank, world, dev):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C3: {n_exp}-exposure {h}x{w}x3 uint16 stack"
-                                   f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, "
+                                   f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}"
+                                   f"{'' if args.max_code == 65535 else f' with codes 0..{args.max_code}'}, "
                                    f"{pairs.n_pairs} pairs, relative loss"},
             "roofline": _train_roofline(pairs.n_pairs, 3 * h * w, elapsed / args.steps),
             **({} if args.no_cpu_baseline else {"cpu_baseline": cpu_baseline_train(args.cpu_seconds)})}

@@ -235,6 +235,50 @@ def test_lut_gradient_vs_eager_oracle_large(dev, h, w, kind):
                   what="gradient tiles")
 
 
+@pytest.mark.parametrize("max_code,n_points", [(4095, 256), (1023, 256), (16383, 64), (65535, 100), (4095, 33)])
+def test_training_kernels_on_codes_below_full_range(dev, max_code, n_points):
+    """10- / 12- / 14-bit data held in uint16 (Normalize(1023 / 4095 / 16383)) and LUT lengths whose step is not a whole number
+    of codes: raw codes with ``max_code`` against the same data normalised with the reference's float32 division and fed
+    as float32 pixels.  A fifth of the codes lie ABOVE max_code (the model clamps them to the top of the curve and the
+    validity mask drops them), codes sit on the thresholds and on LUT knots; both backward kernels."""
+    from clair_torch_amd import ops
+    from clair_torch_amd.common.general_functions import get_valid_exposure_pairs
+    rng = np.random.default_rng(max_code + n_points)
+    n, shape = 9, (3, 24, 64)
+    codes = rng.integers(0, max_code + 1, size=(n,) + shape).astype(np.uint16)
+    flat = codes.reshape(-1)
+    if max_code < 65535:
+        flat[::5] = rng.integers(max_code + 1, min(65536, 2 * max_code + 2), size=flat[::5].shape).astype(np.uint16)
+    lo, hi = 1 / 255, 254 / 255
+    u = np.arange(max_code + 1, dtype=np.float32) / np.float32(max_code)
+    c_lo, c_hi = int(np.argmax(u >= np.float32(lo))), int(max_code - np.argmax(u[::-1] <= np.float32(hi)))
+    knots = np.ceil(np.arange(1, 6) * max_code / (n_points - 1)).astype(np.int64)
+    special = np.concatenate([[c_lo - 1, c_lo, c_lo + 1, c_hi - 1, c_hi, c_hi + 1, 0, max_code, min(max_code + 1, 65535)],
+                              knots, knots - 1]).astype(np.uint16)
+    flat[1:1 + special.size] = special
+    x = (codes.astype(np.float32) / np.float32(max_code)).astype(np.float32)  # CastTo + Normalize as the reference computes them
+    t = torch.tensor(0.002 * 1.3 ** np.arange(n), dtype=torch.float64)
+    i, j, r = get_valid_exposure_pairs(t, 0.25)
+    pairs = ops.PairList(i, j, r, n, dev)
+    lut = torch.stack([torch.linspace(0, 1, n_points) ** p for p in (1.8, 2.2, 2.6)]).to(dev)
+    for rel in (True, False):
+        kw = dict(lut=lut, interp="linear", lower=lo, upper=hi, use_relative=rel, use_unc_weight=False)
+        s_code = ops.pair_residual_sums(torch.from_numpy(codes).to(dev), pairs, level=1, max_code=float(max_code), **kw)
+        s_float = ops.pair_residual_sums(torch.from_numpy(x).to(dev), pairs, level=1, **kw)
+        assert torch.equal(s_code[..., 4], s_float[..., 4]), "mask popcounts differ"
+        assert float(s_code[..., 4].sum()) > 0
+        assert_parity(s_code[..., :3].cpu().numpy(), s_float[..., :3].cpu().numpy(), rtol=1e-5, norm_tol=2e-6,
+                      what=f"code-domain vs generic sums max {max_code} L={n_points} {'rel' if rel else 'abs'}")
+        coef = torch.from_numpy(rng.uniform(0.5, 1.5, size=(pairs.n_pairs, 3))).to(dev)
+        for lane in (True, False):
+            g_code = ops.pair_residual_lut_grad(torch.from_numpy(codes).to(dev), pairs, coef, max_code=float(max_code),
+                                                lane_kernel=lane, **kw)
+            g_float = ops.pair_residual_lut_grad(torch.from_numpy(x).to(dev), pairs, coef, lane_kernel=lane, **kw)
+            gc, gf = g_code.cpu().numpy(), g_float.cpu().numpy()
+            assert rel_norm(gc, gf) <= 2e-5, (max_code, n_points, rel, rel_norm(gc, gf))
+            assert np.abs(gc - gf).max() <= 1e-4 * np.abs(gf).max(), (max_code, n_points, rel)
+
+
 @pytest.mark.parametrize("mode", ["linear", "lookup_fwd", "catmull"])
 def test_many_exposures_narrow_tiles(dev, mode):
     """128 exposures: the kernels fall back to 32-column tiles (LDS budget) and walk the pair list in several launches;
