@@ -312,7 +312,16 @@ __global__ __launch_bounds__(kBlock) void linearize_rgb_kernel(const LinArgs a)
     stage_lut<INTERP>(lds, a.lut, 3, L);
     __syncthreads();
     const uint32_t pv = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
-    if (pv * 12u >= a.q_count) return;
+    // Loads: a thread's own 12 elements are 24 (48) bytes apart from lane to lane, so each of its three load instructions
+    // would touch every cache line of the wavefront's span (measured 4-9 % behind the planar kernel).  Instead the wavefront
+    // reads its 768 elements as three DENSE instructions (lane l takes packets l, 64 + l, 128 + l), parks them in 3 KB of
+    // wave-private LDS and every lane reads its own 12 back (48-byte lane stride: conflict-free for ds_read_b128).  The DS
+    // operations of one wavefront execute in order, so no barrier is needed.
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wave_first = (pv - lane) * 12u;                  // first element of this wavefront, relative to q_begin
+    if (wave_first >= a.q_count) return;                             // (wave-uniform)
+    const bool active = pv * 12u < a.q_count;
+    float *stage = reinterpret_cast<float *>(lds + ((INTERP == CT_INTERP_NONE ? 0 : 3 * L * kEntry) + 15 & ~15)) + wave * 768u;
     const uint32_t m0 = a.q_begin + pv * 12u;  // first memory element of this thread (within one frame)
     const uint32_t pix0 = m0 / 3u;             // local pixel index (m0 is a multiple of 12)
     const float top = (float)(L - 1);
@@ -327,24 +336,33 @@ __global__ __launch_bounds__(kBlock) void linearize_rgb_kernel(const LinArgs a)
     }
     for (uint32_t f = blockIdx.y; f < a.n_frames; f += gridDim.y) {
         float xin[12];
-        if constexpr (sizeof(T) != 4) {
-            const uint64_t base = reinterpret_cast<uint64_t>(a.frames) + (uint64_t)((int64_t)f * a.image_stride * (int64_t)sizeof(T));
+        {
+            LPacket<float, 4> got[3];
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                float part[4];
-                load_codes_as_float<T, 4>(base, (m0 + 4u * h) * (uint32_t)sizeof(T), part);
+                const uint32_t rel = wave_first + 4u * ((uint32_t)h * 64u + lane);  // this lane's packet of dense load h
+                if (rel < a.q_count) {
+                    if constexpr (sizeof(T) != 4) {
+                        const uint64_t base = reinterpret_cast<uint64_t>(a.frames) + (uint64_t)((int64_t)f * a.image_stride * (int64_t)sizeof(T));
+                        load_codes_as_float<T, 4>(base, (a.q_begin + rel) * (uint32_t)sizeof(T), got[h].v);
+                    } else {
+                        const T *src = static_cast<const T *>(a.frames) + (int64_t)f * a.image_stride + a.q_begin + rel;
+                        const LPacket<T, 4> pk = *reinterpret_cast<const LPacket<T, 4> *>(src);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xin[4 * h + k] = part[k];
+                        for (int k = 0; k < 4; ++k) got[h].v[k] = pk.v[k];
+                    }
+                }
             }
-        } else {
-            const T *src = static_cast<const T *>(a.frames) + (int64_t)f * a.image_stride + m0;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) *reinterpret_cast<LPacket<float, 4> *>(stage + 4u * ((uint32_t)h * 64u + lane)) = got[h];
 #pragma unroll
             for (int h = 0; h < 3; ++h) {
-                const LPacket<T, 4> pk = *reinterpret_cast<const LPacket<T, 4> *>(src + 4 * h);
+                const LPacket<float, 4> pk = *reinterpret_cast<const LPacket<float, 4> *>(stage + 12u * lane + 4u * h);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xin[4 * h + k] = pk.v[k];
             }
         }
+        if (!active) continue;  // lanes past the end helped with the loads only
         float lin[12], sd[12];
         [[maybe_unused]] bool tiny = false;
 #pragma unroll
@@ -393,7 +411,8 @@ static int lin_launch_rgb(const LinArgs &a, hipStream_t s)
     uint32_t gy = (a.n_frames + 1) / 2;
     if (gy < 1) gy = 1;
     if (gy > 65535) gy = 65535;
-    const size_t lds = INTERP == CT_INTERP_NONE ? 0 : (size_t)3 * a.n_points * lut_entry_bytes(INTERP);
+    const size_t lds = ((INTERP == CT_INTERP_NONE ? 0 : (size_t)3 * a.n_points * lut_entry_bytes(INTERP)) + 15 & ~(size_t)15) +
+                       (size_t)(kBlock / 64) * 768 * sizeof(float);  // LUT | 3 KB of exchange space per wavefront
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
     hipLaunchKernelGGL((linearize_rgb_kernel<T, INTERP, STD, WRITE_STD>), dim3(gx, gy), dim3(kBlock), lds, s, a);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
