@@ -269,18 +269,20 @@ static size_t exact_fixed_lds(const MergeArgs &a, int interp)
            sizeof(double) * (size_t)a.batch;
 }
 
-// Values kept per sample between the passes: 2 (weight and linearized value) while a workgroup's cache stays within
-// kCacheBudget -- four workgroups per CU --, 1 (the weight: the float64 exp is the expensive half) up to twice that, else 0.
-constexpr size_t kCacheBudget = 37 * 1024;
+// Values kept per sample between the passes: 2 (weight and linearized value) while a workgroup's LDS stays within 37 KB --
+// four workgroups per CU, the occupancy the kernel's registers allow anyway --, else 1 (the weight: the float64 exp is the
+// expensive half) up to 45 KB (three workgroups per CU), else 0.  Measured on C2 through the API (CATMULL, batches of 4 / 8):
+// both values at 44 KB -5 % against no cache, the weight alone at 28 KB -11 %; batches of 8 with the weight at 44 KB -6 %.
+constexpr size_t kCacheBudgetBoth = 37 * 1024, kCacheBudgetWeight = 45 * 1024;
 static int exact_cache_level(const MergeArgs &a, int interp, int weight_mode, int std_mode, int v)
 {
     if (std_mode == CT_STD_NONE) return 0;  // no second pass
     static const bool disabled = getenv("CT_EXACT_NO_CACHE") != nullptr;  // diagnostics: time the two-pass form alone
     if (disabled) return 0;
     const size_t per_level = (size_t)a.batch * v * kBlock * sizeof(float);
-    if (exact_fixed_lds(a, interp) + 2 * per_level <= kCacheBudget) return 2;
+    if (exact_fixed_lds(a, interp) + 2 * per_level <= kCacheBudgetBoth) return 2;
     // the weight alone is only worth keeping when it is an exp
-    if (weight_mode == CT_WEIGHT_GAUSS && exact_fixed_lds(a, interp) + per_level <= kCacheBudget) return 1;
+    if (weight_mode == CT_WEIGHT_GAUSS && exact_fixed_lds(a, interp) + per_level <= kCacheBudgetWeight) return 1;
     return 0;
 }
 
