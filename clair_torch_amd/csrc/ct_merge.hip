@@ -1641,6 +1641,51 @@ extern "C" int ct_hdr_merge_batches(const void *const *stack_devs, const float *
         for (int b = 0; fast && b < n_batches; ++b)
             fast = aligned(stack_devs[b], tsize * kPivotV) && (std_mode != CT_STD_EXPLICIT || aligned(std_devs[b], 4 * kPivotV));
     }
+    // the reference-order kernel walks several batches per launch too (any dtype; packets or single elements)
+    if (!fast && n_batches >= 2 && n_batches <= kMaxMergeBatches && total <= 65536 && (has_state || (first && finalize)) &&
+        interp >= CT_INTERP_LOOKUP && interp <= CT_INTERP_NONE && merge_uses_reference_order(interp, std_mode, flags) &&
+        !(std_mode != CT_STD_NONE && interp == CT_INTERP_LOOKUP && weight_mode == CT_WEIGHT_NONE) &&
+        (dtype == CT_DTYPE_U8 || dtype == CT_DTYPE_U16 || dtype == CT_DTYPE_F32) && geom->channels > 0 && geom->h_tile > 0 &&
+        geom->width > 0 && geom->h_global >= geom->h_tile && geom->row_offset >= 0 &&
+        geom->row_offset + geom->h_tile <= geom->h_global && geom->layout >= CT_LAYOUT_NCHW && geom->layout <= CT_LAYOUT_NHWC_BGR &&
+        (interp == CT_INTERP_NONE || (icrf->lut_dev && icrf->n_points >= 2)) && std_mode >= CT_STD_NONE && std_mode <= CT_STD_EXPLICIT &&
+        (weight_mode == CT_WEIGHT_NONE || weight_mode == CT_WEIGHT_GAUSS) &&
+        (!finalize || (mean_out_dev && (std_mode == CT_STD_NONE || std_out_dev))) &&
+        geom->h_global * geom->width * geom->channels < ((int64_t)1 << 31) && geom->image_stride >= Ql) {
+        const int64_t plane_g = geom->h_global * geom->width, plane_l = geom->h_tile * geom->width;
+        MergeArgs a{};
+        a.stack = stack_devs[0];
+        a.std_stack = std_mode == CT_STD_EXPLICIT ? std_devs[0] : nullptr;
+        a.exposure = exposure_dev;
+        a.lut = icrf->lut_dev;
+        a.mean_state = has_state ? mean_state_dev : nullptr;
+        a.sumw_state = has_state ? sumw_state_dev : nullptr;
+        a.var_state = has_state ? var_state_dev : nullptr;
+        a.mean_out = mean_out_dev;
+        a.std_out = std_out_dev;
+        a.image_stride = geom->image_stride;
+        a.tile.plane_local = (uint32_t)plane_l;
+        a.tile.chan_skip = (uint32_t)(plane_g - plane_l);
+        a.tile.base = (uint32_t)(geom->row_offset * geom->width);
+        a.tile.layout = (uint32_t)geom->layout;
+        a.tile.channels = (uint32_t)geom->channels;
+        a.batch = (int32_t)total;
+        a.channels = geom->channels;
+        a.n_points = interp == CT_INTERP_NONE ? 2 : icrf->n_points;
+        a.std_value = std_value;
+        a.weight_scale = 30.0f;
+        a.inv_max_code = 1.0f;
+        a.flags = flags;
+        if (dtype != CT_DTYPE_F32 && ct_norm_constants(max_code, &a.norm.hi, &a.norm.lo) != CT_OK) return CT_ERR_UNSUPPORTED;
+        MergeBatches mb{};
+        mb.n_batches = n_batches;
+        for (int b = 0; b < n_batches; ++b) {
+            mb.batch_size[b] = batch_sizes[b];
+            mb.batch_ptr[b] = stack_devs[b];
+            mb.std_ptr[b] = std_mode == CT_STD_EXPLICIT ? std_devs[b] : nullptr;
+        }
+        return merge_reference_order(a, dtype, (uint32_t)Ql, interp, weight_mode, std_mode, static_cast<hipStream_t>(stream), &mb);
+    }
     if (!fast && (flags & CT_MERGE_REQUIRE_ONE_LAUNCH)) return CT_ERR_UNSUPPORTED;  // (tests: make the route explicit)
     if (!fast) {
         // one launch per batch with the state in memory (exactly what the caller would have done)

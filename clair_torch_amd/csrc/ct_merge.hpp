@@ -37,9 +37,21 @@ struct alignas(sizeof(T) * V) Packet {
 };
 
 
-// ct_merge_exact.hip: the merge with the reference's float32 autograd order (two passes over the batch); `q_count` elements
-// from `q_begin`, dispatched on dtype / interpolation / weight / std mode.  Returns a CT_* status.
+// Several consecutive batches in one launch (ct_hdr_merge_batches): batch b has batch_size[b] exposures at batch_ptr[b]
+// (explicit uncertainties at std_ptr[b]); the exposure times of all batches follow each other in MergeArgs::exposure and
+// MergeArgs::batch is their total.  n_batches == 0: the one batch MergeArgs itself describes.
+constexpr int kMaxMergeBatches = 16;
+struct MergeBatches {
+    int32_t n_batches;
+    int32_t batch_size[kMaxMergeBatches];
+    const void *batch_ptr[kMaxMergeBatches];
+    const float *std_ptr[kMaxMergeBatches];
+};
+
+// ct_merge_exact.hip: the merge with the reference's float32 autograd order (two passes over each batch); `q_count` elements
+// from `q_begin`, dispatched on dtype / interpolation / weight / std mode.  With `batches` the launch walks them with the
+// streaming state in registers in between (bit-identical to one launch per batch).  Returns a CT_* status.
 int merge_reference_order(const MergeArgs &a, int dtype, uint32_t q_total, int interp, int weight_mode, int std_mode,
-                          hipStream_t stream);
+                          hipStream_t stream, const MergeBatches *batches = nullptr);
 
 }  // namespace ct

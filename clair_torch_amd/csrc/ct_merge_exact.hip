@@ -27,6 +27,7 @@
 // Cost: two passes over the batch (the second mostly from L2 / Infinity Cache), a float64 exp per sample and pass and the
 // float64 scalar chain: 3-5x the time of the fast kernels.  Roofline: not bandwidth -- float64 VALU.  It is a parity instrument for the
 // modes whose reference result is dominated by float32 cancellation, not the headline path.
+#include <algorithm>
 #include <cstdlib>
 #include "ct_merge.hpp"
 
@@ -111,31 +112,35 @@ __device__ __forceinline__ float sqrt_correctly_rounded(float v)
 // and was measured slower than not caching at all: 5.4 against 3.9 ms on C2 LOOKUP -- the per-exposure overhead of the
 // loop is then paid per sample.)
 template <typename T, int V, int INTERP, int WEIGHT, int STD, int CACHE = 0>
-__global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const MergeArgs a)
+__global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const MergeArgs a, const MergeBatches mb)
 {
     extern __shared__ __align__(16) char lds[];
     constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
     constexpr bool kHasStd = STD != CT_STD_NONE;
     constexpr int kEntry = lut_entry_bytes(INTERP);
-    const int C = a.channels, L = a.n_points, B = a.batch;
+    const int C = a.channels, L = a.n_points;
+    const int n_exposures = a.batch;  // of all batches of the launch
     stage_lut<INTERP, false>(lds, a.lut, C, L);
     // 1 / t_n in float64, once per workgroup: y_n = lin_n / t_n and G_n = (g_S w_n) / t_n are formed as products with it
     // (at most one float64 ulp from the divisions the reference performs, i.e. invisible after the float32 casts except on
     // ~1e-9 of the samples) -- three float64 divisions per sample were a quarter of this kernel's time
     double *inv_t = reinterpret_cast<double *>(lds + ((INTERP == CT_INTERP_NONE ? 0 : C * L * kEntry) + 7 & ~7));
-    for (int n = threadIdx.x; n < B; n += kBlock) inv_t[n] = 1.0 / a.exposure[n];
-    [[maybe_unused]] float *wc = reinterpret_cast<float *>(inv_t + B) + threadIdx.x;   // + (n * V + e) * kBlock: conflict-free
-    [[maybe_unused]] float *lc = wc + (size_t)B * V * kBlock;
+    for (int n = threadIdx.x; n < n_exposures; n += kBlock) inv_t[n] = 1.0 / a.exposure[n];
+    int b_max = n_exposures;  // largest batch: the cache arrays are sized for it (host: exact_launch)
+    if (mb.n_batches > 0) {
+        b_max = 0;
+        for (int k = 0; k < mb.n_batches; ++k) b_max = mb.batch_size[k] > b_max ? mb.batch_size[k] : b_max;
+    }
+    [[maybe_unused]] float *wc = reinterpret_cast<float *>(inv_t + n_exposures) + threadIdx.x;   // + (n * V + e) * kBlock: conflict-free
+    [[maybe_unused]] float *lc = wc + (size_t)b_max * V * kBlock;
     __syncthreads();
     const float top = INTERP == CT_INTERP_NONE ? 1.0f : (float)(L - 1);
-    const bool first = a.flags & CT_MERGE_FIRST_BATCH, finalize = a.flags & CT_MERGE_FINALIZE;
+    const bool fresh = a.flags & CT_MERGE_FIRST_BATCH, finalize = a.flags & CT_MERGE_FINALIZE;
     const bool keep_state = a.mean_state != nullptr;
 
     const uint32_t vec = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     if (vec * (uint32_t)V >= a.q_count) return;
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
-    const T *src = static_cast<const T *>(a.stack) + q0;
-    const float *ssrc = STD == CT_STD_EXPLICIT ? a.std_stack + q0 : nullptr;
 
     uint32_t qp[V];       // planar index of each element (state, outputs)
     const char *row[V];   // its LUT row in LDS
@@ -157,6 +162,25 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
         lin = icrf_sample<INTERP, true, false>(x, r, top, unused);       // base.py:135-226, un-fused
     };
 
+    // The streaming state: read once, carried in registers over the batches of the launch (internal_detach, hdr_merge.py:128:
+    // a batch's result is the next batch's state), written once.
+    double state_mean[V];
+    float state_w[V], state_var[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        state_mean[e] = fresh ? 0.0 : a.mean_state[qp[e]];
+        state_w[e] = fresh ? 0.0f : a.sumw_state[qp[e]];
+        state_var[e] = (fresh || !kHasStd) ? 0.0f : a.var_state[qp[e]];
+    }
+    const int n_batches = mb.n_batches > 0 ? mb.n_batches : 1;
+    int n_first = 0;  // first exposure of the current batch among the launch's exposures
+    for (int bi = 0; bi < n_batches; ++bi) {
+    const int B = mb.n_batches > 0 ? mb.batch_size[bi] : n_exposures;
+    const T *src = static_cast<const T *>(mb.n_batches > 0 ? mb.batch_ptr[bi] : a.stack) + q0;
+    const float *ssrc = STD == CT_STD_EXPLICIT ? (mb.n_batches > 0 ? mb.std_ptr[bi] : a.std_stack) + q0 : nullptr;
+    const bool first = fresh && bi == 0;
+    const double *inv_tb = inv_t + n_first;
+
     // ---- pass 1: W_b (float32, torch.sum order), S = sum w y (float64) ----
     TorchRowSum Wsum[V];
     double S[V];
@@ -164,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
     for (int e = 0; e < V; ++e) S[e] = 0.0;
     for (int n = 0; n < B; ++n) {
         const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)n * a.image_stride);
-        const double it = inv_t[n];
+        const double it = inv_tb[n];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             float x, xm, w, lin;
@@ -185,13 +209,13 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
         Wb[e] = Wsum[e].total();
         D[e] = Wb[e] + 1e-6f;                                            // float32 tensor + Python float
         const double mb = S[e] / (double)D[e];
-        const float WA = first ? 0.0f : a.sumw_state[qp[e]];
-        const double meanA = first ? 0.0 : a.mean_state[qp[e]];
+        const float WA = first ? 0.0f : state_w[e];
+        const double meanA = first ? 0.0 : state_mean[e];
         Wt[e] = WA + Wb[e];
         frac[e] = __fdiv_rn(Wb[e], Wt[e]);
         const double diff = mb - meanA;
         mean[e] = meanA + (double)frac[e] * diff;
-        var_in[e] = (first || !kHasStd) ? 0.0f : a.var_state[qp[e]];
+        var_in[e] = (first || !kHasStd) ? 0.0f : state_var[e];
         if constexpr (kHasStd) {
             const float g_frac = (float)diff;                             // d mean / d frac, cast at the float32 tensor
             g_s[e] = (double)frac[e] / (double)D[e];                      // d mean / d S
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
             const Packet<T, V> pk = *reinterpret_cast<const Packet<T, V> *>(src + (int64_t)n * a.image_stride);
             Packet<float, V> sp;
             if constexpr (STD == CT_STD_EXPLICIT) sp = *reinterpret_cast<const Packet<float, V> *>(ssrc + (int64_t)n * a.image_stride);
-            const double it = inv_t[n];
+            const double it = inv_tb[n];
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float x, xm, w, lin;
@@ -248,17 +272,26 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
 
 #pragma unroll
     for (int e = 0; e < V; ++e) {
+        state_mean[e] = mean[e];
+        state_w[e] = Wt[e];
+        if constexpr (kHasStd) state_var[e] = var_o[e];
+    }
+    n_first += B;
+    }  // batches
+
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
         if (keep_state) {
-            a.mean_state[qp[e]] = mean[e];
-            a.sumw_state[qp[e]] = Wt[e];
-            if constexpr (kHasStd) a.var_state[qp[e]] = var_o[e];
+            a.mean_state[qp[e]] = state_mean[e];
+            a.sumw_state[qp[e]] = state_w[e];
+            if constexpr (kHasStd) a.var_state[qp[e]] = state_var[e];
         }
         if (finalize) {
             if (a.flags & CT_MERGE_MEAN_OUT_F32)
-                static_cast<float *>(a.mean_out)[qp[e]] = (float)mean[e];
+                static_cast<float *>(a.mean_out)[qp[e]] = (float)state_mean[e];
             else
-                static_cast<double *>(a.mean_out)[qp[e]] = mean[e];
-            if constexpr (kHasStd) a.std_out[qp[e]] = sqrt_correctly_rounded(var_o[e]);   // hdr_merge.py:155
+                static_cast<double *>(a.mean_out)[qp[e]] = state_mean[e];
+            if constexpr (kHasStd) a.std_out[qp[e]] = sqrt_correctly_rounded(state_var[e]);   // hdr_merge.py:155
         }
     }
 }
@@ -274,109 +307,123 @@ static size_t exact_fixed_lds(const MergeArgs &a, int interp)
 // expensive half) up to 45 KB (three workgroups per CU), else 0.  Measured on C2 through the API (CATMULL, batches of 4 / 8):
 // both values at 44 KB -5 % against no cache, the weight alone at 28 KB -11 %; batches of 8 with the weight at 44 KB -6 %.
 constexpr size_t kCacheBudgetBoth = 37 * 1024, kCacheBudgetWeight = 45 * 1024;
-static int exact_cache_level(const MergeArgs &a, int interp, int weight_mode, int std_mode, int v)
+static int exact_cache_level(const MergeArgs &a, int b_max, int interp, int weight_mode, int std_mode, int v)
 {
     if (std_mode == CT_STD_NONE) return 0;  // no second pass
     static const bool disabled = getenv("CT_EXACT_NO_CACHE") != nullptr;  // diagnostics: time the two-pass form alone
     if (disabled) return 0;
-    const size_t per_level = (size_t)a.batch * v * kBlock * sizeof(float);
+    const size_t per_level = (size_t)b_max * v * kBlock * sizeof(float);  // (b_max: the largest batch of the launch)
     if (exact_fixed_lds(a, interp) + 2 * per_level <= kCacheBudgetBoth) return 2;
     // the weight alone is only worth keeping when it is an exp
     if (weight_mode == CT_WEIGHT_GAUSS && exact_fixed_lds(a, interp) + per_level <= kCacheBudgetWeight) return 1;
     return 0;
 }
 
+struct ExactRoute {
+    MergeBatches mb;  // n_batches == 0: the single batch of MergeArgs
+    int b_max;        // exposures of the largest batch
+};
+
 template <typename T, int V, int INTERP, int WEIGHT, int STD, int CACHE = 0>
-static int exact_launch(const MergeArgs &a, hipStream_t s)
+static int exact_launch(const MergeArgs &a, const ExactRoute &r, hipStream_t s)
 {
     if (a.q_count == 0) return CT_OK;
     const uint32_t vecs = (a.q_count + V - 1) / V, grid = (vecs + kBlock - 1) / kBlock;
-    const size_t lds = exact_fixed_lds(a, INTERP) + (size_t)CACHE * a.batch * V * kBlock * sizeof(float);
+    const size_t lds = exact_fixed_lds(a, INTERP) + (size_t)CACHE * r.b_max * V * kBlock * sizeof(float);
     if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
-    hipLaunchKernelGGL((merge_reference_order_kernel<T, V, INTERP, WEIGHT, STD, CACHE>), dim3(grid), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((merge_reference_order_kernel<T, V, INTERP, WEIGHT, STD, CACHE>), dim3(grid), dim3(kBlock), lds, s, a, r.mb);
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
 template <typename T, int V, int INTERP, int WEIGHT>
-static int exact_std(const MergeArgs &a, int std_mode, hipStream_t s)
+static int exact_std(const MergeArgs &a, const ExactRoute &r, int std_mode, hipStream_t s)
 {
     if constexpr (V == 4) {  // the cached variants (packets only; ragged tails are a handful of elements)
-        const int level = exact_cache_level(a, INTERP, WEIGHT, std_mode, V);
+        const int level = exact_cache_level(a, r.b_max, INTERP, WEIGHT, std_mode, V);
         if (level == 2) {
             switch (std_mode) {
-                case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, 2>(a, s);
-                case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, 2>(a, s);
-                case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, 2>(a, s);
+                case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, 2>(a, r, s);
+                case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, 2>(a, r, s);
+                case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, 2>(a, r, s);
             }
         } else if (level == 1) {
             switch (std_mode) {
-                case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, 1>(a, s);
-                case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, 1>(a, s);
-                case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, 1>(a, s);
+                case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT, 1>(a, r, s);
+                case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER, 1>(a, r, s);
+                case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT, 1>(a, r, s);
             }
         }
     }
     switch (std_mode) {
-        case CT_STD_NONE: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, s);
-        case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, s);
-        case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER>(a, s);
-        case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT>(a, s);
+        case CT_STD_NONE: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_NONE>(a, r, s);
+        case CT_STD_CONSTANT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_CONSTANT>(a, r, s);
+        case CT_STD_MULTIPLIER: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_MULTIPLIER>(a, r, s);
+        case CT_STD_EXPLICIT: return exact_launch<T, V, INTERP, WEIGHT, CT_STD_EXPLICIT>(a, r, s);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
 
 template <typename T, int V>
-static int exact_interp(const MergeArgs &a, int interp, int weight_mode, int std_mode, hipStream_t s)
+static int exact_interp(const MergeArgs &a, const ExactRoute &r, int interp, int weight_mode, int std_mode, hipStream_t s)
 {
     const bool gauss = weight_mode == CT_WEIGHT_GAUSS;
     switch (interp) {
         case CT_INTERP_LOOKUP:
-            return gauss ? exact_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_GAUSS>(a, std_mode, s)
-                         : exact_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_NONE>(a, std_mode, s);
+            return gauss ? exact_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_GAUSS>(a, r, std_mode, s)
+                         : exact_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_NONE>(a, r, std_mode, s);
         case CT_INTERP_LINEAR:
-            return gauss ? exact_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS>(a, std_mode, s)
-                         : exact_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_NONE>(a, std_mode, s);
+            return gauss ? exact_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_GAUSS>(a, r, std_mode, s)
+                         : exact_std<T, V, CT_INTERP_LINEAR, CT_WEIGHT_NONE>(a, r, std_mode, s);
         case CT_INTERP_CATMULL:
-            return gauss ? exact_std<T, V, CT_INTERP_CATMULL, CT_WEIGHT_GAUSS>(a, std_mode, s)
-                         : exact_std<T, V, CT_INTERP_CATMULL, CT_WEIGHT_NONE>(a, std_mode, s);
+            return gauss ? exact_std<T, V, CT_INTERP_CATMULL, CT_WEIGHT_GAUSS>(a, r, std_mode, s)
+                         : exact_std<T, V, CT_INTERP_CATMULL, CT_WEIGHT_NONE>(a, r, std_mode, s);
         case CT_INTERP_NONE:
-            return gauss ? exact_std<T, V, CT_INTERP_NONE, CT_WEIGHT_GAUSS>(a, std_mode, s)
-                         : exact_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE>(a, std_mode, s);
+            return gauss ? exact_std<T, V, CT_INTERP_NONE, CT_WEIGHT_GAUSS>(a, r, std_mode, s)
+                         : exact_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE>(a, r, std_mode, s);
     }
     return CT_ERR_INVALID_ARGUMENT;
 }
 
 template <typename T>
-static int exact_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s)
+static int exact_typed(MergeArgs a, const ExactRoute &r, uint32_t Q, int interp, int weight_mode, int std_mode, hipStream_t s)
 {
     // packets of 4 where every exposure's packet is naturally aligned; the rest (and everything, on odd strides) one by one
     constexpr int V = 4;
     auto aligned = [](const void *p, size_t bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
-    const bool vec_ok = aligned(a.stack, sizeof(T) * V) && (a.image_stride % V) == 0 && aligned(a.std_stack, 4 * V);
+    bool vec_ok = aligned(a.stack, sizeof(T) * V) && (a.image_stride % V) == 0 && aligned(a.std_stack, 4 * V);
+    for (int b = 0; b < r.mb.n_batches; ++b) vec_ok = vec_ok && aligned(r.mb.batch_ptr[b], sizeof(T) * V) && aligned(r.mb.std_ptr[b], 4 * V);
     const uint32_t q_vec = vec_ok ? (Q / V) * V : 0;
     int rc = CT_OK;
     if (q_vec) {
         a.q_begin = 0;
         a.q_count = q_vec;
-        rc = exact_interp<T, V>(a, interp, weight_mode, std_mode, s);
+        rc = exact_interp<T, V>(a, r, interp, weight_mode, std_mode, s);
         if (rc != CT_OK) return rc;
     }
     if (q_vec < Q) {
         a.q_begin = q_vec;
         a.q_count = Q - q_vec;
-        rc = exact_interp<T, 1>(a, interp, weight_mode, std_mode, s);
+        rc = exact_interp<T, 1>(a, r, interp, weight_mode, std_mode, s);
     }
     return rc;
 }
 
 int merge_reference_order(const MergeArgs &a, int dtype, uint32_t q_total, int interp, int weight_mode, int std_mode,
-                          hipStream_t stream)
+                          hipStream_t stream, const MergeBatches *batches)
 {
     if (a.batch > 65536) return CT_ERR_TOO_LARGE;  // TorchRowSum's level width
+    ExactRoute r{};
+    r.b_max = a.batch;
+    if (batches && batches->n_batches > 0) {
+        if (batches->n_batches > kMaxMergeBatches) return CT_ERR_INVALID_ARGUMENT;
+        r.mb = *batches;
+        r.b_max = 0;
+        for (int b = 0; b < batches->n_batches; ++b) r.b_max = std::max(r.b_max, (int)batches->batch_size[b]);
+    }
     switch (dtype) {
-        case CT_DTYPE_U8: return exact_typed<uint8_t>(a, q_total, interp, weight_mode, std_mode, stream);
-        case CT_DTYPE_U16: return exact_typed<uint16_t>(a, q_total, interp, weight_mode, std_mode, stream);
-        case CT_DTYPE_F32: return exact_typed<float>(a, q_total, interp, weight_mode, std_mode, stream);
+        case CT_DTYPE_U8: return exact_typed<uint8_t>(a, r, q_total, interp, weight_mode, std_mode, stream);
+        case CT_DTYPE_U16: return exact_typed<uint16_t>(a, r, q_total, interp, weight_mode, std_mode, stream);
+        case CT_DTYPE_F32: return exact_typed<float>(a, r, q_total, interp, weight_mode, std_mode, stream);
     }
     return CT_ERR_UNSUPPORTED;
 }

@@ -742,8 +742,9 @@ def test_merge_batches_one_launch_equals_one_launch_per_batch(dev, dtype, max_co
 
 
 def test_merge_batches_falls_back_where_one_launch_cannot_run(dev):
-    """Odd plane sizes (no whole packets), float32 pixels, CATMULL: ct_hdr_merge_batches walks the batches with one launch
-    each -- same results as the explicit loop; with require_one_launch it says so instead."""
+    """Odd plane sizes (no whole packets), float32 pixels, CATMULL without uncertainties (the generic kernel):
+    ct_hdr_merge_batches walks the batches with one launch each -- same results as the explicit loop; with
+    require_one_launch it says so instead."""
     from clair_torch_amd import ops
     rng = np.random.default_rng(5)
     n, c, h, w = 9, 3, 7, 9
@@ -753,16 +754,72 @@ def test_merge_batches_falls_back_where_one_launch_cannot_run(dev):
              (torch.from_numpy(rng.random((n, c, 8, 8), dtype=np.float32)).to(dev), "linear"),
              (torch.from_numpy(rng.integers(0, 65536, size=(n, c, 8, 8)).astype(np.uint16)).to(dev), "catmull")]
     for stack, mode in cases:
-        kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode="multiplier", std_value=0.05)
+        std_mode = "none" if mode == "catmull" else "multiplier"
+        kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode=std_mode, std_value=0.05)
         parts = [(0, 4), (4, 6), (6, 9)]
-        st = ops.MergeState(tuple(stack.shape[1:]), dev, True)
+        st = ops.MergeState(tuple(stack.shape[1:]), dev, std_mode != "none")
         for k, (a, b) in enumerate(parts):
             ref = ops.hdr_merge_batch(stack[a:b], torch.from_numpy(t[a:b]), state=st, finalize=k == 2, **kw)
         got = ops.hdr_merge_batches([stack[a:b] for a, b in parts], [torch.from_numpy(t[a:b]) for a, b in parts], **kw)
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert torch.equal(got[0], ref[0]) and (std_mode == "none" or torch.equal(got[1], ref[1]))
         with pytest.raises(RuntimeError, match="unsupported"):
             ops.hdr_merge_batches([stack[a:b] for a, b in parts], [torch.from_numpy(t[a:b]) for a, b in parts],
                                   require_one_launch=True, **kw)
+
+
+@pytest.mark.parametrize("kind,shape", [("u16", (12, 32)), ("u16", (7, 9)), ("f32", (8, 8)), ("u8", (5, 12))])
+@pytest.mark.parametrize("mode,std_mode", [("catmull", "multiplier"), ("lookup", "constant"), ("catmull", "explicit"),
+                                           ("linear", "multiplier")])
+def test_merge_batches_reference_order_one_launch(dev, kind, shape, mode, std_mode):
+    """The reference-order kernel (default for LOOKUP / CATMULL uncertainties; LINEAR on request) walks several batches per
+    launch as well, the streaming state in registers in between: bit for bit what one launch per batch gives -- shuffled
+    batch composition, unequal sizes incl. one of 1 and one of 9 exposures (LDS cache levels 2, 1 and 0 inside one launch),
+    packets and odd planes, integer codes and float pixels, explicit uncertainties, a second call continuing from a
+    MergeState -- and the recorded-order emulation's numbers are those of the per-batch route by construction."""
+    from clair_torch_amd import ops
+    rng = np.random.default_rng(sum(shape) + len(mode))
+    n, c = 21, 3
+    h, w = shape
+    t = 0.0005 * 2.0 ** (np.arange(n) / 3.0)
+    if kind == "f32":
+        stack = torch.from_numpy(rng.random((n, c, h, w), dtype=np.float32)).to(dev)
+    else:
+        hi = 256 if kind == "u8" else 65536
+        stack = torch.from_numpy(rng.integers(0, hi, size=(n, c, h, w)).astype(np.uint8 if kind == "u8" else np.uint16)).to(dev)
+    sd_d = torch.from_numpy((0.002 + 0.03 * rng.random((n, c, h, w))).astype(np.float32)).to(dev)
+    lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]).to(dev)
+    kw = dict(lut=lut, interp=mode, gaussian_weight=True, reference_order=True)
+    if std_mode != "explicit":
+        kw.update(std_mode=std_mode, std_value=0.01 if std_mode == "constant" else 0.05)
+    order = rng.permutation(n)
+    cuts = [0, 4, 5, 14, 17, 21]   # batch sizes 4 1 9 3 4
+    batches = [sorted(order[a:b].tolist(), key=lambda i: t[i]) for a, b in zip(cuts[:-1], cuts[1:])]
+
+    def one_per_batch(bs, state):
+        res = None
+        for k, idx in enumerate(bs):
+            res = ops.hdr_merge_batch(torch.stack([stack[i] for i in idx]), torch.from_numpy(t[idx]), state=state,
+                                      finalize=k == len(bs) - 1,
+                                      std=torch.stack([sd_d[i] for i in idx]) if std_mode == "explicit" else None, **kw)
+        return res
+
+    def one_launch(bs, state, finalize=True):
+        stds = [torch.stack([sd_d[i] for i in idx]) for idx in bs] if std_mode == "explicit" else None
+        return ops.hdr_merge_batches([torch.stack([stack[i] for i in idx]) for idx in bs], [torch.from_numpy(t[idx]) for idx in bs],
+                                     stds=stds, state=state, finalize=finalize, require_one_launch=True, **kw)
+
+    ref = one_per_batch(batches, ops.MergeState((c, h, w), dev, True))
+    got = one_launch(batches, None)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    st = ops.MergeState((c, h, w), dev, True)
+    assert one_launch(batches[:2], st, finalize=False) is None
+    got2 = one_launch(batches[2:], st)
+    assert torch.equal(got2[0], ref[0]) and torch.equal(got2[1], ref[1])
+    # small batches only: the cached variants carry the state too
+    small = [b for b in batches if len(b) <= 4]
+    ref_s = one_per_batch(small, ops.MergeState((c, h, w), dev, True))
+    got_s = one_launch(small, None)
+    assert torch.equal(got_s[0], ref_s[0]) and torch.equal(got_s[1], ref_s[1])
 
 
 @pytest.mark.parametrize("dtype", ["u8", "u16"])
