@@ -131,7 +131,9 @@ int ct_hdr_merge_batch(const void *stack_dev, int32_t dtype, float max_code, int
  * CT_MERGE_FINALIZE on the last one when set in `flags`), bit for bit.  Where the pivoted code-domain kernel applies and
  * every batch is packet-aligned (n_batches <= 16) it is ONE launch that keeps (mean, sum of weights, variance) in
  * registers between the batches -- the reference's default batch_size: 4 (scripts/config.yaml) otherwise moves 32 B of
- * state per element and batch beside 8 B of samples; anything else runs one launch per batch.
+ * state per element and batch beside 8 B of samples.  The reference-order kernel (CT_MERGE_REFERENCE_ORDER, the default
+ * of LOOKUP / CATMULL with uncertainties) does the same for any dtype and alignment.  Anything else runs one launch per
+ * batch.
  *   stack_devs / std_devs / batch_sizes  HOST arrays of n_batches device pointers / sizes (std_devs NULL unless EXPLICIT);
  *                                        every batch is (B_b, C, H_tile, W) with the common geometry, sorted as collate does
  *   exposure_dev                         the exposure times of all batches, concatenated in the same order (device)
