@@ -568,8 +568,11 @@ constexpr float kRoughLimit = 64.0f;  // |A| / max(|g[i]|, |g[i+1]|) above which
 // four floats per packet instead of two packed dwords the 64-VGPR build spills 19 registers (1.24 ms); 7 and 6
 // wavefronts measure the same within 1 % (0.856 / 0.865 ms sustained, profiles/r02_typed_load_ab.log).  Raw-code
 // builds (CT_PIVOT_TYPED_LOAD=0) fit 64.  The state-carrying kernels keep the default allocation.
+#ifndef CT_RGB252_WAVES
+#define CT_RGB252_WAVES 6
+#endif
 #ifndef CT_PIVOT_KERNEL_ATTR
-#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? (RGB252 ? 6 : 7) : 8) : 4, 8)))
+#define CT_PIVOT_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(FIRST && V <= 4 && STD != CT_STD_EXPLICIT ? (CT_PIVOT_TYPED_LOAD ? (RGB252 ? CT_RGB252_WAVES : 7) : 8) : 4, 8)))
 #endif
 // MULTI: the launch walks x.n_batches consecutive batches per element with (mean, sum of weights, variance) in registers and
 // the per-batch recurrence of WBOMean (statistics.py:64-109, state detached after every batch, hdr_merge.py:128) applied
@@ -1069,55 +1072,72 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         }
         if (finalize && rgb252) {
             if constexpr (RGB252) {
-                // Regroup the wavefront's results by channel plane through LDS (wave-private; the DS operations of one
-                // wavefront execute in order, so no barrier): the wavefront's 256 consecutive memory elements contain up to
-                // 21 whole groups of 12 elements = 4 pixels x 3 channels; lane 3 i + c takes plane c of group i and writes
-                // its four consecutive pixels as 16-byte packets.  The <= 11 elements before the first and after the last
-                // whole group are stored one by one by the lanes that own them.  (A mapping that gives every wavefront 252
-                // elements = 84 whole pixels was measured first: its 504-byte wave loads cost 11 % more HBM fetch.)
-                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-                char *stage = lds + x.stage_off + wave * 3072u;
-                double *sm = reinterpret_cast<double *>(stage);            // 256 means in memory order
-                float *ss = reinterpret_cast<float *>(stage + 2048);       // 256 standard uncertainties
-                typedef double d2 __attribute__((ext_vector_type(2)));
-                typedef float f4 __attribute__((ext_vector_type(4)));
+                // Regroup the WORKGROUP's results by channel plane through LDS: a full tile's 1024 consecutive memory
+                // elements contain 84-85 whole groups of 12 elements = 4 pixels x 3 channels; thread 3 i + c takes plane c of
+                // group i and writes its four consecutive pixels as 16-byte packets.  Only the <= 11 elements before the first
+                // and after the last whole group of the TILE are stored one by one (1 % of the elements; regrouping per
+                // wavefront left 4 % of them to such partial-line stores: FETCH_SIZE +11 %, WRITE_SIZE +8 %,
+                // profiles/r03_layout_ingest.md).  Two workgroup barriers per tile; the ragged last tile of the image, where
+                // threads have left the loop, stores element by element.  (A mapping that gives every wavefront 252 elements
+                // = 84 whole pixels was measured first: its 504-byte wave loads cost 11 % more HBM fetch.)
+                const uint32_t tile_first = tile * (uint32_t)(kBlock * V);     // relative to q_begin (0 in this mode)
+                const bool tile_full = tile_first + (uint32_t)(kBlock * V) <= a.q_count;   // workgroup-uniform
                 float sdv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sdv[e] = kHasStd ? __builtin_amdgcn_sqrtf(var_o[e]) : 0.0f;
-                d2 m01 = {mean_o[0], mean_o[1]}, m23 = {mean_o[2], mean_o[3]};
-                *reinterpret_cast<d2 *>(sm + 4u * lane) = m01;
-                *reinterpret_cast<d2 *>(sm + 4u * lane + 2) = m23;
-                if constexpr (kHasStd) {
-                    f4 sv = {sdv[0], sdv[1], sdv[2], sdv[3]};
-                    *reinterpret_cast<f4 *>(ss + 4u * lane) = sv;
-                }
-                const uint32_t wave_first = q0 - 4u * lane - a.q_begin;    // first memory element of this wavefront
-                const uint32_t wave_end = wave_first + 256u < a.q_count ? wave_first + 256u : a.q_count;
-                const uint32_t g_first = (wave_first + 11u) / 12u, g_end = wave_end / 12u;   // whole groups [g_first, g_end)
+                if (tile_full) {
+                    char *stage = lds + x.stage_off;
+                    double *sm = reinterpret_cast<double *>(stage);            // 1024 means in memory order
+                    float *ss = reinterpret_cast<float *>(stage + 8192);       // 1024 standard uncertainties
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    __syncthreads();  // the previous tile's readers are done with the stage
+                    d2 m01 = {mean_o[0], mean_o[1]}, m23 = {mean_o[2], mean_o[3]};
+                    *reinterpret_cast<d2 *>(sm + 4u * threadIdx.x) = m01;
+                    *reinterpret_cast<d2 *>(sm + 4u * threadIdx.x + 2) = m23;
+                    if constexpr (kHasStd) {
+                        f4 sv = {sdv[0], sdv[1], sdv[2], sdv[3]};
+                        *reinterpret_cast<f4 *>(ss + 4u * threadIdx.x) = sv;
+                    }
+                    __syncthreads();
+                    const uint32_t g_first = (tile_first + 11u) / 12u, g_end = (tile_first + (uint32_t)(kBlock * V)) / 12u;   // whole groups
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {   // the ragged ends of the wavefront's range
-                    const uint32_t m = q0 + (uint32_t)e - a.q_begin;
-                    if (m < 12u * g_first || m >= 12u * g_end) {
+                    for (int e = 0; e < 4; ++e) {   // the ragged ends of the tile
+                        const uint32_t m = q0 + (uint32_t)e - a.q_begin;
+                        if (m < 12u * g_first || m >= 12u * g_end) {
+                            const uint32_t q = planar_of(q0 + e);
+                            static_cast<double *>(a.mean_out)[q] = mean_o[e];
+                            if constexpr (kHasStd) a.std_out[q] = sdv[e];
+                        }
+                    }
+                    // plane-major: threads 0 .. n-1 take plane 0 of the tile's n groups, the next n plane 1, ... -- consecutive
+                    // lanes then store consecutive 32-byte packets of ONE plane (whole lines per wavefront; group-major
+                    // threads 3 i + c alternated between the planes: WRITE_SIZE +20 %)
+                    const uint32_t n_groups = g_end - g_first;               // 84 or 85: 3 n <= 256 threads
+                    const uint32_t c = (threadIdx.x >= n_groups ? 1u : 0u) + (threadIdx.x >= 2u * n_groups ? 1u : 0u);
+                    const uint32_t tri = threadIdx.x - c * n_groups;
+                    if (threadIdx.x < 3u * n_groups) {
+                        const uint32_t g = g_first + tri;                      // global group: pixels 4 g .. 4 g + 3
+                        const uint32_t cm = a.tile.layout == CT_LAYOUT_NHWC_BGR ? 2u - c : c;
+                        const uint32_t local = 12u * g - tile_first + cm;     // index of (pixel 4 g, memory channel cm) in the stage
+                        Packet<double, 4> mo;
+                        Packet<float, 4> so;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            mo.v[j] = sm[local + 3u * (uint32_t)j];
+                            if constexpr (kHasStd) so.v[j] = ss[local + 3u * (uint32_t)j];
+                        }
+                        const size_t dst = (size_t)c * a.tile.plane_local + 4u * (size_t)g;
+                        store_stream(reinterpret_cast<Packet<double, 4> *>(static_cast<double *>(a.mean_out) + dst), mo);
+                        if constexpr (kHasStd) store_stream(reinterpret_cast<Packet<float, 4> *>(a.std_out + dst), so);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
                         const uint32_t q = planar_of(q0 + e);
                         static_cast<double *>(a.mean_out)[q] = mean_o[e];
                         if constexpr (kHasStd) a.std_out[q] = sdv[e];
                     }
-                }
-                const uint32_t tri = lane / 3u, c = lane - 3u * tri;
-                if (g_first + tri < g_end) {
-                    const uint32_t g = g_first + tri;                      // global group: pixels 4 g .. 4 g + 3
-                    const uint32_t cm = a.tile.layout == CT_LAYOUT_NHWC_BGR ? 2u - c : c;
-                    const uint32_t local = 12u * g - wave_first + cm;     // index of (pixel 4 g, memory channel cm) in the stage
-                    Packet<double, 4> mo;
-                    Packet<float, 4> so;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        mo.v[j] = sm[local + 3u * (uint32_t)j];
-                        if constexpr (kHasStd) so.v[j] = ss[local + 3u * (uint32_t)j];
-                    }
-                    const size_t dst = (size_t)c * a.tile.plane_local + 4u * (size_t)g;
-                    store_stream(reinterpret_cast<Packet<double, 4> *>(static_cast<double *>(a.mean_out) + dst), mo);
-                    if constexpr (kHasStd) store_stream(reinterpret_cast<Packet<float, 4> *>(a.std_out + dst), so);
                 }
             }
         } else if (finalize && !planar) {
