@@ -188,7 +188,7 @@ def run_merge(args, rank, world, dev):
         codes = (codes.flip(1) if args.layout == "nhwc_bgr" else codes).permute(0, 2, 3, 1).contiguous()
         if "std" in kw:
             kw["std"] = (kw["std"].flip(1) if args.layout == "nhwc_bgr" else kw["std"]).permute(0, 2, 3, 1).contiguous()
-        kw.update(layout=args.layout)
+        kw.update(layout=args.layout, out_layout=args.out_layout)
 
     def band_stats(mean, std):
         # per channel: min, max, sum of the mean and of the std -- one fused pass (ct_band_stats; torch's reductions took
@@ -254,7 +254,7 @@ def run_merge(args, rank, world, dev):
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}: {n_exp}-exposure {h}x{w}x3 {'uint16' if args.input == 'u16' else 'float32'} stack per GPU"
-                               f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order'}, "
+                               f"{'' if args.layout == 'nchw' else ' in ' + args.layout.upper() + ' memory order' + (' (outputs in the same order)' if args.out_layout == 'input' else '')}, "
                                f"merge{'' if args.std == 'none' else '+uncertainty'} ({args.interp.upper()} ICRF 3x256"
                                f"{'' if args.max_code == 65535 else ', Normalize(' + str(args.max_code) + ')'}, Gaussian weights, "
                                f"sigma: {args.std}, float64 mean + float32 std out)"
@@ -767,6 +767,8 @@ def main():
     ap.add_argument("--max-code", type=int, default=65535, choices=[65535, 16383, 4095, 1023],
                     help="merge: what Normalize divides the uint16 codes by (12-bit camera data: 4095)")
     ap.add_argument("--interp", default="linear", choices=["linear", "lookup", "catmull"], help="merge: ICRF interpolation mode")
+    ap.add_argument("--out-layout", default="planar", choices=["planar", "input"],
+                    help="merge with an interleaved --layout: outputs planar (C,H,W) like the reference, or in the input's own (H,W,C) order (CT_MERGE_OUT_AS_INPUT)")
     ap.add_argument("--layout", default="nchw", choices=["nchw", "nhwc", "nhwc_bgr"],
                     help="merge / linearize: memory order of the stack (nhwc = as decoded, nhwc_bgr = OpenCV's channel order)")
     ap.add_argument("--exposures", type=int, default=32)

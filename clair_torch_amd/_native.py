@@ -16,7 +16,7 @@ STD_NONE, STD_CONSTANT, STD_MULTIPLIER, STD_EXPLICIT = 0, 1, 2, 3
 WEIGHT_NONE, WEIGHT_GAUSS = 0, 1
 LAYOUT_NCHW, LAYOUT_NHWC, LAYOUT_NHWC_BGR = 0, 1, 2
 MERGE_FIRST_BATCH, MERGE_FINALIZE, MERGE_MEAN_OUT_F32, MERGE_F64_MOMENTS = 1, 2, 4, 8
-MERGE_REFERENCE_ORDER, MERGE_CLOSED_FORM, MERGE_STD_HINT, MERGE_REQUIRE_ONE_LAUNCH = 16, 32, 64, 128
+MERGE_REFERENCE_ORDER, MERGE_CLOSED_FORM, MERGE_STD_HINT, MERGE_REQUIRE_ONE_LAUNCH, MERGE_OUT_AS_INPUT = 16, 32, 64, 128, 256
 ERR_NO_GRADIENT_PATH = -4
 
 ABI_VERSION = 3

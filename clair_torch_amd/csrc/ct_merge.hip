@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < V; ++e) p[e] = (float)a.mean_state[a.tile.planar_index(q0 + e)];
+            for (int e = 0; e < V; ++e) p[e] = (float)a.mean_state[a.out_index(q0 + e)];
         }
     }
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     [[maybe_unused]] bool bad[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        const uint32_t q = a.tile.planar_index(q0 + e);  // state and outputs are planar (C, H, W)
+        const uint32_t q = a.out_index(q0 + e);  // state and outputs are planar (C, H, W) unless CT_MERGE_OUT_AS_INPUT
         float Wb = W[e];
         if constexpr (!kGauss) Wb = (float)B;
         const float Df = Wb + 1e-6f;  // float32 tensor + python float stays float32 (statistics.py:79-80)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     if (keep_state) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const uint32_t q = a.tile.planar_index(q0 + e);
+            const uint32_t q = a.out_index(q0 + e);
             a.mean_state[q] = mean_o[e];
             a.sumw_state[q] = W[e];
             if constexpr (kHasStd) a.var_state[q] = std_o[e];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void merge_kernel(const MergeArgs a)
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) std_o[e] = __builtin_amdgcn_sqrtf(std_o[e]);
-    if (finalize && a.tile.layout != CT_LAYOUT_NCHW) {
+    if (finalize && a.tile.layout != CT_LAYOUT_NCHW && !(a.flags & CT_MERGE_OUT_AS_INPUT)) {
         // interleaved input: the V elements of this thread belong to different planes -> element-wise stores
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -672,6 +672,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     const bool finalize = a.flags & CT_MERGE_FINALIZE;
     const bool keep_state = a.mean_state != nullptr;
     const bool planar = a.tile.layout == CT_LAYOUT_NCHW;
+    const bool planar_out = planar || (a.flags & CT_MERGE_OUT_AS_INPUT);  // state / outputs at the memory index itself
     float fsf = 1.0f;  // scale of the folded moments back to true units
     if constexpr (kGauss) fsf = K / kk;
     if constexpr (STD == CT_STD_CONSTANT) fsf *= a.std_value;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
         const uint32_t voff = q0 * (uint32_t)sizeof(T), svoff = q0 * 4u;
         // planar (state / output) index of memory element m: the identity for planar stacks, constant divisors for RGB / BGR
         auto planar_of = [&](uint32_t m) -> uint32_t {
-            if (planar) return m;
+            if (planar_out) return m;
             if (C == 3) {
                 uint32_t c, pixel;
                 a.tile.interleaved3(m, c, pixel);
@@ -1140,7 +1141,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     }
                 }
             }
-        } else if (finalize && !planar) {
+        } else if (finalize && !planar_out) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const uint32_t q = planar_of(q0 + e);
@@ -1215,7 +1216,7 @@ static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
         if constexpr (V == 4 && CT_PIVOT_TYPED_LOAD) {
             // interleaved RGB / BGR, the whole image in this launch, outputs only (no streaming state): packet stores
             auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; };
-            if (a.tile.layout != CT_LAYOUT_NCHW && a.channels == 3 && a.tile.plane_local % 4 == 0 && !a.mean_state &&
+            if (a.tile.layout != CT_LAYOUT_NCHW && !(a.flags & CT_MERGE_OUT_AS_INPUT) && a.channels == 3 && a.tile.plane_local % 4 == 0 && !a.mean_state &&
                 (a.flags & CT_MERGE_FINALIZE) && !(a.flags & CT_MERGE_MEAN_OUT_F32) && a.q_begin == 0 &&
                 a.q_count == 3u * a.tile.plane_local && aligned16(a.mean_out) && aligned16(a.std_out)) {
                 x.rgb252 = 1;

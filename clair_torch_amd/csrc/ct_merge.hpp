@@ -27,6 +27,11 @@ struct MergeArgs {
     float std_value;
     float weight_scale;   // Gaussian scale (30)
     uint32_t flags;
+    // index of memory element m of one image in the state / output arrays: planar (C, H, W) unless CT_MERGE_OUT_AS_INPUT
+    __device__ __forceinline__ uint32_t out_index(uint32_t m) const
+    {
+        return (flags & CT_MERGE_OUT_AS_INPUT) ? m : tile.planar_index(m);
+    }
 };
 
 constexpr float kPivotCondLimit = 8.0f;  // sum |terms| / result above which a wavefront repeats the batch about the mean

@@ -142,14 +142,14 @@ __global__ __launch_bounds__(kBlock) void merge_reference_order_kernel(const Mer
     if (vec * (uint32_t)V >= a.q_count) return;
     const uint32_t q0 = a.q_begin + vec * (uint32_t)V;
 
-    uint32_t qp[V];       // planar index of each element (state, outputs)
+    uint32_t qp[V];       // index of each element in the state / output arrays (planar unless CT_MERGE_OUT_AS_INPUT)
     const char *row[V];   // its LUT row in LDS
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        qp[e] = a.tile.planar_index(q0 + e);
+        qp[e] = a.out_index(q0 + e);
         int ch;
         uint32_t qg;
-        a.tile.locate(qp[e], ch, qg);
+        a.tile.locate(a.tile.planar_index(q0 + e), ch, qg);
         row[e] = lds + (INTERP == CT_INTERP_NONE ? 0 : lut_row<INTERP>(qg, ch, C) * L * kEntry);
     }
 

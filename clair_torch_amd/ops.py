@@ -51,6 +51,13 @@ def _chw(stack: torch.Tensor, layout: str):
     return stack.shape[3], stack.shape[1], stack.shape[2]
 
 
+def _out_shape(stack: torch.Tensor, layout: str, out_layout: str):
+    """Shape of the merge's state / outputs: planar (C,H,W), or the stack's own per-image shape with out_layout "input"."""
+    if out_layout not in ("planar", "input"):
+        raise ValueError(f"unknown out_layout {out_layout!r} (planar, input)")
+    return tuple(stack.shape[1:]) if out_layout == "input" else tuple(_chw(stack, layout))
+
+
 def _geometry(stack: torch.Tensor, tile: Optional[TileGeometry], layout: str = "nchw") -> nv.Geometry:
     c, h, w = _chw(stack, layout)
     hg, r0 = (h, 0) if tile is None else (tile.h_global, tile.row_offset)
@@ -97,13 +104,15 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
                     std: Optional[torch.Tensor] = None, std_mode: str = "none", std_value: float = 0.0,
                     max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
                     tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw",
-                    force_f64_moments: bool = False, reference_order: Optional[bool] = None):
+                    force_f64_moments: bool = False, reference_order: Optional[bool] = None, out_layout: str = "planar"):
     """One batch of the HDR merge (ct_hdr_merge_batch).  Returns (mean, std|None) when ``finalize`` else None.
 
     stack (B,C,H,W) uint8/uint16 codes (give ``max_code``) or float32 pixels; exposures (B) any float dtype.
     ``state`` carries the streaming state across batches (None = single-batch merge).
     ``layout`` "nhwc" / "nhwc_bgr": the stack is (B,H,W,C) as OpenCV decodes it (an explicit std stack likewise);
-    outputs stay planar (C,H,W).
+    outputs stay planar (C,H,W) -- unless ``out_layout="input"`` (extension, CT_MERGE_OUT_AS_INPUT): state and outputs
+    then have the stack's own memory order, (H,W,C) in the input's channel order, which is what an OpenCV writer wants
+    and lets the kernel store dense packets without regrouping (the MergeState must then be created with that shape).
     ``force_f64_moments`` (diagnostic, CT_MERGE_F64_MOMENTS): keep the float64-moment kernel where the pivoted
     float32 one would run (tests compare the two).
     ``reference_order``: True = evaluate the uncertainty in the reference's own float32 autograd order
@@ -152,12 +161,17 @@ def hdr_merge_batch(stack: torch.Tensor, exposures: torch.Tensor, *, lut: Option
         flags |= nv.MERGE_MEAN_OUT_F32
     elif mean_dtype != torch.float64:
         raise TypeError("mean_dtype must be float64 (reference) or float32")
+    out_shape = _out_shape(stack, layout, out_layout)
+    if out_layout == "input":
+        flags |= nv.MERGE_OUT_AS_INPUT
     if state is None and not finalize:
         raise ValueError("a non-final batch needs a MergeState")
     if state is not None and has_std and state.var is None:
         raise ValueError("MergeState was created without a variance buffer")
-    mean_out = torch.empty((c, h, w), dtype=mean_dtype, device=dev) if finalize else None
-    std_out = torch.empty((c, h, w), dtype=torch.float32, device=dev) if (finalize and has_std) else None
+    if state is not None and tuple(state.mean.shape) != out_shape:
+        raise ValueError(f"MergeState has shape {tuple(state.mean.shape)}, this merge needs {out_shape}")
+    mean_out = torch.empty(out_shape, dtype=mean_dtype, device=dev) if finalize else None
+    std_out = torch.empty(out_shape, dtype=torch.float32, device=dev) if (finalize and has_std) else None
     with torch.cuda.device(dev):
         rc = nv.load().ct_hdr_merge_batch(
             _ptr(stack), _DTYPE[stack.dtype], float(max_code or 1.0), b, ctypes.byref(geom), _ptr(std), _STD[std_mode],
@@ -179,14 +193,14 @@ def hdr_merge_batches(stacks, exposures, *, lut: Optional[torch.Tensor] = None, 
                       gaussian_weight: bool = True, stds=None, std_mode: str = "none", std_value: float = 0.0,
                       max_code: Optional[float] = None, state: Optional[MergeState] = None, finalize: bool = True,
                       tile: Optional[TileGeometry] = None, mean_dtype: torch.dtype = torch.float64, layout: str = "nchw",
-                      reference_order: Optional[bool] = None, require_one_launch: bool = False):
+                      reference_order: Optional[bool] = None, require_one_launch: bool = False, out_layout: str = "planar"):
     """Several CONSECUTIVE batches of one merge in one call (ct_hdr_merge_batches): the same result, bit for bit, as
     hdr_merge_batch on each of them in turn with ``state`` carried along -- but where the pivoted code-domain kernel
     applies the streaming state stays in registers between the batches (one launch, no state traffic).
 
     ``stacks``: list of (B_k,C,H,W) device tensors of one dtype / geometry (each sorted by exposure like custom_collate);
     ``exposures``: list of (B_k) tensors; ``stds``: list of explicit std tensors or None.  At most MAX_MERGE_BATCHES.
-    ``require_one_launch`` (tests): raise instead of falling back to one launch per batch.
+    ``require_one_launch`` (tests): raise instead of falling back to one launch per batch.  ``out_layout``: as in hdr_merge_batch.
     Returns (mean, std|None) when ``finalize`` else None."""
     k = len(stacks)
     if k == 0 or k != len(exposures) or (stds is not None and len(stds) != k):
@@ -197,7 +211,7 @@ def hdr_merge_batches(stacks, exposures, *, lut: Optional[torch.Tensor] = None, 
         return hdr_merge_batch(stacks[0], exposures[0], lut=lut, interp=interp, gaussian_weight=gaussian_weight,
                                std=None if stds is None else stds[0], std_mode=std_mode, std_value=std_value, max_code=max_code,
                                state=state, finalize=finalize, tile=tile, mean_dtype=mean_dtype, layout=layout,
-                               reference_order=reference_order)
+                               reference_order=reference_order, out_layout=out_layout)
     for t in stacks:
         _check_stack(t)
         if t.dtype != stacks[0].dtype or t.shape[1:] != stacks[0].shape[1:] or t.device != stacks[0].device:
@@ -230,6 +244,9 @@ def hdr_merge_batches(stacks, exposures, *, lut: Optional[torch.Tensor] = None, 
         flags |= nv.MERGE_REFERENCE_ORDER if reference_order else nv.MERGE_CLOSED_FORM
     if require_one_launch:
         flags |= nv.MERGE_REQUIRE_ONE_LAUNCH
+    out_shape = _out_shape(stacks[0], layout, out_layout)
+    if out_layout == "input":
+        flags |= nv.MERGE_OUT_AS_INPUT
     if mean_dtype == torch.float32:
         flags |= nv.MERGE_MEAN_OUT_F32
     elif mean_dtype != torch.float64:
@@ -238,11 +255,13 @@ def hdr_merge_batches(stacks, exposures, *, lut: Optional[torch.Tensor] = None, 
         raise ValueError("a non-final call needs a MergeState")
     if state is None:
         # several batches: whatever cannot run as one launch walks them with the state in memory
-        state = MergeState((c, h, w), dev, has_std)
+        state = MergeState(out_shape, dev, has_std)
     if has_std and state.var is None:
         raise ValueError("MergeState was created without a variance buffer")
-    mean_out = torch.empty((c, h, w), dtype=mean_dtype, device=dev) if finalize else None
-    std_out = torch.empty((c, h, w), dtype=torch.float32, device=dev) if (finalize and has_std) else None
+    if tuple(state.mean.shape) != out_shape:
+        raise ValueError(f"MergeState has shape {tuple(state.mean.shape)}, this merge needs {out_shape}")
+    mean_out = torch.empty(out_shape, dtype=mean_dtype, device=dev) if finalize else None
+    std_out = torch.empty(out_shape, dtype=torch.float32, device=dev) if (finalize and has_std) else None
     ptr_arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in stacks])
     std_arr = (ctypes.c_void_p * k)(*[sd.data_ptr() for sd in stds]) if stds is not None else None
     size_arr = (ctypes.c_int32 * k)(*sizes)

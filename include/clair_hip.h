@@ -70,6 +70,11 @@ extern "C" {
 #define CT_MERGE_CLOSED_FORM 32u     /* keep the fast closed-form kernels for LOOKUP / CATMULL with uncertainties as well */
 #define CT_MERGE_REQUIRE_ONE_LAUNCH 128u /* ct_hdr_merge_batches: CT_ERR_UNSUPPORTED instead of one launch per batch */
 #define CT_MERGE_STD_HINT 64u        /* ct_hdr_merge_kernel_name only: uncertainties are propagated */
+#define CT_MERGE_OUT_AS_INPUT 256u   /* extension: state and outputs in the MEMORY ORDER OF THE INPUT stack instead of planar
+                                        (C, H, W): an interleaved (H, W, C) RGB / BGR stack then gives (H, W, C) outputs in the
+                                        same channel order -- what an OpenCV writer wants (the reference's save path permutes
+                                        back, common/general_functions.py:338-358) -- and the merge stores dense packets
+                                        without regrouping.  Use the same flag on every batch of a merge. */
 
 /* Memory layout of one image of a stack.  Outputs and state are always planar (C, H, W) like the reference's tensors.
  * NHWC = the interleaved layout OpenCV decodes to (clair_torch/common/data_io.py:125-154); NHWC_BGR additionally

@@ -302,3 +302,44 @@ def test_training_and_video_api_with_cv_to_torch_transform(dev):
     for a, b in zip(runs[1][1][1:3], runs[0][1][1:3]):
         assert_parity(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-9, norm_tol=1e-10, what="measure_linearity")
     assert torch.equal(runs[1][2][0], runs[0][2][0]) and torch.equal(runs[1][2][1], runs[0][2][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.uint16, torch.float32])
+@pytest.mark.parametrize("mode,std_mode,ref_order", [("linear", "multiplier", None), ("lookup", "constant", False), ("catmull", "multiplier", None),
+                                                      ("catmull", "none", None), (None, "multiplier", None)])
+def test_merge_outputs_in_the_input_order(dev, dtype, mode, std_mode, ref_order):
+    """CT_MERGE_OUT_AS_INPUT (extension): state and outputs of an interleaved merge in the stack's own (H,W,C) order -- the
+    same numbers as the planar outputs, permuted (and channel-flipped for BGR); one batch, a streamed MergeState of that
+    shape, several batches per launch, an odd image (no whole packets), every kernel family (pivot, generic, reference order)."""
+    from clair_torch_amd import ops
+    rng = np.random.default_rng(11)
+    for (n, c, h, w) in ((6, 3, 16, 24), (5, 3, 7, 9)):
+        if dtype == torch.float32:
+            planar = torch.from_numpy(rng.random((n, c, h, w), dtype=np.float32)).to(dev)
+        else:
+            planar = _stack(rng, n, c, h, w, dtype).to(dev)
+        t = torch.tensor([0.001 * 2.0 ** k for k in range(n)], dtype=torch.float64)
+        lut = None if mode is None else torch.stack([torch.linspace(0, 1, 256) ** (1.8 + 0.3 * k) for k in range(c)]).to(dev)
+        kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode=std_mode, std_value=0.05, reference_order=ref_order)
+        has_std = std_mode != "none"
+        mean_p, std_p = ops.hdr_merge_batch(planar, t, **kw)
+        for layout, stack in (("nhwc", planar.permute(0, 2, 3, 1).contiguous()), ("nhwc_bgr", planar.flip(1).permute(0, 2, 3, 1).contiguous())):
+            def as_planar(x):
+                x = x.permute(2, 0, 1)
+                return x.flip(0) if layout == "nhwc_bgr" else x
+            mean_i, std_i = ops.hdr_merge_batch(stack, t, layout=layout, out_layout="input", **kw)
+            assert mean_i.shape == (h, w, c) and mean_i.is_contiguous()
+            assert torch.equal(as_planar(mean_i), mean_p) and (not has_std or torch.equal(as_planar(std_i), std_p))
+            # streamed: a MergeState of the input's shape; then the same batches in one call
+            st = ops.MergeState((h, w, c), dev, has_std)
+            ops.hdr_merge_batch(stack[:2], t[:2], state=st, finalize=False, layout=layout, out_layout="input", **kw)
+            m2, s2 = ops.hdr_merge_batch(stack[2:], t[2:], state=st, finalize=True, layout=layout, out_layout="input", **kw)
+            st_p = ops.MergeState((c, h, w), dev, has_std)
+            ops.hdr_merge_batch(planar[:2], t[:2], state=st_p, finalize=False, **kw)
+            m2p, s2p = ops.hdr_merge_batch(planar[2:], t[2:], state=st_p, finalize=True, **kw)
+            assert torch.equal(as_planar(m2), m2p) and (not has_std or torch.equal(as_planar(s2), s2p))
+            m3, s3 = ops.hdr_merge_batches([stack[:2], stack[2:]], [t[:2], t[2:]], layout=layout, out_layout="input", **kw)
+            assert torch.equal(m3, m2) and (not has_std or torch.equal(s3, s2))
+            with pytest.raises(ValueError, match="MergeState has shape"):
+                ops.hdr_merge_batch(stack[:2], t[:2], state=ops.MergeState((c, h, w), dev, has_std), finalize=False, layout=layout,
+                                    out_layout="input", **kw)
