@@ -17,6 +17,7 @@ PY
 run merge_c2 --gpus 1 --steps 20 --warmup 5
 run merge_c2_nhwc --steps 20 --warmup 5 --no-cpu-baseline --layout nhwc
 run merge_c2_nhwc_bgr --steps 20 --warmup 5 --no-cpu-baseline --layout nhwc_bgr
+run merge_c2_nhwc_bgr_out_as_input --steps 20 --warmup 5 --no-cpu-baseline --layout nhwc_bgr --out-layout input
 run merge_c2_max4095 --steps 20 --warmup 5 --no-cpu-baseline --max-code 4095
 run merge_c2_f32 --steps 20 --warmup 5 --no-cpu-baseline --input f32
 run merge_c2_lookup --steps 20 --warmup 5 --no-cpu-baseline --interp lookup
