@@ -18,7 +18,8 @@ from ._staging import normalise_transform_list, resolve_device, stage_images, st
 
 def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFModelBase] = None,
                       weight_fn: Optional[Callable] = None, flat_field_dataset=None, gpu_transforms=None,
-                      dark_field_dataset=None, tile: Optional[ops.TileGeometry] = None, group=None):
+                      dark_field_dataset=None, tile: Optional[ops.TileGeometry] = None, group=None,
+                      output_layout: str = "planar"):
     """Merge the exposure stack served by ``dataloader`` into an HDR image and its standard uncertainty.
 
     Returns ``(mean float64 (C,H,W), std float32 (C,H,W) | None)`` on ``device`` (squeezed like the reference).
@@ -29,7 +30,15 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
     own variance term (inference/dark_field.py; parity unpinned -- the blur is torchvision's, restated).
     ``tile`` / ``group`` (extensions): the rows this process holds of a taller global image (multi-GPU row bands) and
     the process group over which the flat field's spatial sums are all-reduced and the blur's halo rows exchanged.
+    ``output_layout`` (extension): "planar" = the reference's (C,H,W); "input" = when the frames are ingested interleaved
+    (``gpu_transforms`` starting with CvToTorch on raw (H,W,3) frames), leave mean and uncertainty in that (H,W,C) order and
+    channel sequence -- what ``cv2.imwrite`` takes; the kernel then stores dense packets (CT_MERGE_OUT_AS_INPUT).  Not
+    combinable with flat-field / dark-field correction, whose kernels work on planar data.
     """
+    if output_layout not in ("planar", "input"):
+        raise ValueError(f"unknown output_layout {output_layout!r} (planar, input)")
+    if output_layout == "input" and (flat_field_dataset is not None or dark_field_dataset is not None):
+        raise ValueError('output_layout="input" cannot be combined with flat-field / dark-field correction')
     expect(dataloader, DataLoader, "dataloader")
     expect(device, (str, torch.device), "device")
     expect(icrf_model, ICRFModelBase, "icrf_model", allow_none=True)
@@ -61,14 +70,17 @@ def compute_hdr_image(dataloader: DataLoader, device, icrf_model: Optional[ICRFM
         if not queue:
             return
         k0 = queue[0]
+        out_layout = "input" if (output_layout == "input" and k0["layout"] != "nchw") else "planar"
         if state is None and (not final or flat_field_dataset is not None):
-            chw = tuple(k0["images"].shape[1:]) if k0["layout"] == "nchw" else (k0["images"].shape[3], k0["images"].shape[1], k0["images"].shape[2])
+            chw = tuple(k0["images"].shape[1:]) if (k0["layout"] == "nchw" or out_layout == "input") else \
+                (k0["images"].shape[3], k0["images"].shape[1], k0["images"].shape[2])
             state = ops.MergeState(chw, dev, with_variance=k0["std_mode"] != "none")
         stds = None if k0["std"] is None else [q["std"] for q in queue]
         result = ops.hdr_merge_batches([q["images"] for q in queue], [q["exposure"] for q in queue], lut=lut, interp=interp,
                                        gaussian_weight=weight_fn is not None, stds=stds, std_mode=k0["std_mode"],
                                        std_value=k0["std_value"], max_code=k0["max_code"], state=state,
-                                       finalize=final and flat_field_dataset is None, tile=tile, layout=k0["layout"])
+                                       finalize=final and flat_field_dataset is None, tile=tile, layout=k0["layout"],
+                                       out_layout=out_layout)
         queue = []
 
     while pending is not None:

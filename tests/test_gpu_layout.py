@@ -122,6 +122,11 @@ def test_public_api_with_cv_to_torch_transform(dev):
     got = compute_hdr_image(DataLoader(RawFrames(raw, t), batch_size=3, collate_fn=custom_collate), "cuda", model,
                             weight_fn=gaussian_value_weights, gpu_transforms=[CvToTorch()] + norm)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    # output_layout="input": mean / uncertainty stay (H,W,C) BGR -- what cv2.imwrite takes -- with the same numbers
+    cv_out = compute_hdr_image(DataLoader(RawFrames(raw, t), batch_size=3, collate_fn=custom_collate), "cuda", model,
+                               weight_fn=gaussian_value_weights, gpu_transforms=[CvToTorch()] + norm, output_layout="input")
+    assert cv_out[0].shape == (20, 28, 3)
+    assert torch.equal(cv_out[0].flip(-1).permute(2, 0, 1), ref[0]) and torch.equal(cv_out[1].flip(-1).permute(2, 0, 1), ref[1])
 
     class Identity(BaseTransform):
         def __call__(self, x):
