@@ -348,3 +348,8 @@ def test_merge_outputs_in_the_input_order(dev, dtype, mode, std_mode, ref_order)
             with pytest.raises(ValueError, match="MergeState has shape"):
                 ops.hdr_merge_batch(stack[:2], t[:2], state=ops.MergeState((c, h, w), dev, has_std), finalize=False, layout=layout,
                                     out_layout="input", **kw)
+            # a row band with the global geometry (multi-GPU tiles): the band's rows of the whole result
+            r0 = h // 3
+            mb, sb = ops.hdr_merge_batch(stack[:, r0:].contiguous(), t, layout=layout, out_layout="input",
+                                         tile=ops.TileGeometry(h_global=h, row_offset=r0), **kw)
+            assert torch.equal(mb, mean_i[r0:]) and (not has_std or torch.equal(sb, std_i[r0:]))
