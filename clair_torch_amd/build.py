@@ -17,9 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libclair_hip.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")   # per-source objects (git-ignored), so one edited kernel recompiles alone
-SOURCES = ["ct_merge.hip", "ct_merge_exact.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_flatfield.hip", "ct_stats.hip", "ct_darkfield.hip", "ct_bandstats.hip",
+SOURCES = ["ct_merge.hip", "ct_merge_multi.hip", "ct_merge_exact.hip", "ct_linearize.hip", "ct_pairs.hip", "ct_flatfield.hip", "ct_stats.hip", "ct_darkfield.hip", "ct_bandstats.hip",
            "ct_api.cpp"]
 HEADERS = ["ct_device.hpp", "ct_merge.hpp", os.path.join("..", "..", "include", "clair_hip.h")]
+EXTRA_DEPS = {"ct_merge_multi.hip": ["ct_merge.hip"]}  # sources that include another source verbatim
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
@@ -44,7 +45,8 @@ def _object_is_stale(src, obj):
     if not os.path.exists(obj):
         return True
     built = os.path.getmtime(obj)
-    return any(os.path.getmtime(d) > built for d in [src] + [os.path.join(CSRC, h) for h in HEADERS])
+    extra = [os.path.join(CSRC, e) for e in EXTRA_DEPS.get(os.path.basename(src), [])]
+    return any(os.path.getmtime(d) > built for d in [src] + extra + [os.path.join(CSRC, h) for h in HEADERS])
 
 
 def build(force=False, verbose=False):

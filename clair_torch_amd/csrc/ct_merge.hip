@@ -24,6 +24,14 @@
 #include "ct_merge.hpp"
 #include <type_traits>
 
+// The file compiles as two translation units so that the two halves of its (many) kernel instantiations build in parallel:
+// CT_MERGE_PART 0 (this file as given to the compiler): everything but the several-batches-per-launch instantiations of
+// merge_pivot_kernel; CT_MERGE_PART 1 (ct_merge_multi.hip = this file with the macro set): those, behind
+// ct::merge_pivot_multi.  CT_MERGE_PART 2 (tools/merge_bench.hip, which includes this file verbatim): both.
+#ifndef CT_MERGE_PART
+#define CT_MERGE_PART 0
+#endif
+
 namespace ct {
 
 // Arithmetic of one sample, written so that every constant factor is folded out of the loop:
@@ -586,17 +594,22 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
     static_assert(!RGB252 || (V == 4 && FIRST && !MULTI && CT_PIVOT_TYPED_LOAD), "RGB252: single-batch packets of the typed-load kernel");
     extern __shared__ __align__(16) char lds[];
     static_assert(sizeof(T) != 4, "raw integer codes only");
-    static_assert(INTERP != CT_INTERP_CATMULL, "CATMULL uses merge_kernel / merge_reference_order_kernel");
-    static_assert(CT_PIVOT_TYPED_LOAD || (INTERP != CT_INTERP_LOOKUP && !CLAMP), "raw-load build: whole-step LINEAR only");
-    constexpr bool kLut = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;  // a table in LDS
+    static_assert(CT_PIVOT_TYPED_LOAD || ((INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_NONE) && !CLAMP), "raw-load build: whole-step LINEAR only");
+    constexpr bool kLut = INTERP != CT_INTERP_NONE;  // a table in LDS
     constexpr bool kLookup = INTERP == CT_INTERP_LOOKUP;  // piecewise constant: entry j = half interval j, slope 0, row = channel
+    // CATMULL (r03): entry i holds the interval's cubic in the code offset, f = d + o (c + o (b + o a)), o = code - i step --
+    // the Catmull-Rom basis of base.py:199-224 on the taps g[i-1..i+2] (edges replicated) collected by powers of t = o / step
+    // in float64 and rounded once; three FMAs for the value, four more instructions for df/dcode.  The closed-form kernel
+    // for CATMULL stacks WITHOUT uncertainties (and with CT_MERGE_CLOSED_FORM); the default with uncertainties stays
+    // the reference-order kernel.
+    constexpr bool kCat = INTERP == CT_INTERP_CATMULL;
     constexpr bool kHasStd = STD != CT_STD_NONE;
     constexpr bool kGauss = WEIGHT == CT_WEIGHT_GAUSS;
     constexpr bool kTyped = CT_PIVOT_TYPED_LOAD;  // codes arrive as floats from typed buffer loads
     using CodePk = std::conditional_t<kTyped, Packet<float, V>, Packet<T, V>>;
     const int C = a.channels, L = a.n_points, B = a.batch;
-    constexpr int kWV = (kLut && kGauss && kTyped && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;  // weight evaluation variant
-    constexpr int kEntryShift = kWV == 2 ? 4 : 3;
+    constexpr int kWV = (INTERP == CT_INTERP_LINEAR && kGauss && kTyped && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;  // weight evaluation variant
+    constexpr int kEntryShift = (kWV == 2 || kCat) ? 4 : 3;
     const int E = kLut ? (int)x.n_entries : 0;  // table entries per row
     const int lut_bytes = C * E * (1 << kEntryShift);
     float2 *expo = reinterpret_cast<float2 *>(lds + lut_bytes);  // per exposure {1 / t_n, chain factor of the y' term}
@@ -617,6 +630,19 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             const int r = k / E, j = k - r * E;
             const int idx = (j + 1) >> 1;
             reinterpret_cast<float2 *>(lds)[k] = make_float2(a.lut[(size_t)r * L + (idx < L ? idx : L - 1)], 0.0f);
+        }
+    } else if constexpr (kCat) {
+        const int total = C * L;
+        const double st = (double)x.step;
+        for (int k = threadIdx.x; k < total; k += kBlock) {
+            const int r = k / L, i = k - r * L;
+            const float *row = a.lut + (size_t)r * L;
+            const double p0 = row[i > 0 ? i - 1 : 0], p1 = row[i], p2 = row[i + 1 < L ? i + 1 : L - 1], p3 = row[i + 2 < L ? i + 2 : L - 1];
+            // w0 p0 + w1 p1 + w2 p2 + w3 p3 with the basis of base.py:199-224 = p1 + t c + t^2 b + t^3 a
+            const double c1 = 0.5 * (p2 - p0), b1 = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3), a1 = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
+            // (entry L - 1 is met at offset 0 only -- code == max_code, where the reference's clamp still passes the gradient
+            // -- or, with CLAMP, by codes above max_code, whose offset and slope are zeroed in the loop)
+            reinterpret_cast<float4 *>(lds)[k] = make_float4((float)p1, (float)(c1 / st), (float)(b1 / (st * st)), (float)(a1 / (st * st * st)));
         }
     } else if constexpr (kLut) {
         // entry i of row r: f(code) = A + S * code on [i * step, (i + 1) * step):  S = (g[i+1] - g[i]) / step (the
@@ -773,7 +799,12 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
             for (int e = 0; e < V; ++e) {
                 const float px = pk.v[e];
                 float lin = px * a.inv_max_code;
-                if constexpr (kLut) {
+                if constexpr (kCat) {
+                    const float4 g = *reinterpret_cast<const float4 *>(lds + lds_entry_address<kEntryShift>(tf[e], rowc[e]));
+                    float o = __builtin_fmaf(tf[e] - floor_magic, -x.step, px);
+                    if constexpr (CLAMP) o = px > x.max_code ? 0.0f : o;
+                    lin = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(g.w, o, g.z), o, g.y), o, g.x);
+                } else if constexpr (kLut) {
                     const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address<kEntryShift>(tf[e], rowc[e]));
                     lin = __builtin_fmaf(g.y, rough ? __builtin_fmaf(tf[e] - floor_magic, -x.step, px) : px, g.x);
                 }
@@ -868,6 +899,20 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                             gw[e] = g.z;
                             gd[e] = g.w;
                             pxl[e] = __builtin_fmaf(tf[e] - floor_magic, -x.step, pxv[e]);  // delta = code - i * step, exact
+                        } else if constexpr (kCat) {
+                            const float4 g = *reinterpret_cast<const float4 *>(lds + lds_entry_address<4>(tf[e], rowc[e]));
+                            float o = __builtin_fmaf(tf[e] - floor_magic, -x.step, pxv[e]);  // code - i * step
+                            [[maybe_unused]] bool above = false;  // a code above max_code: the model clamps it to the top, gradient 0
+                            if constexpr (CLAMP) {
+                                above = pxv[e] > x.max_code;
+                                o = above ? 0.0f : o;
+                            }
+                            ga[e] = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(g.w, o, g.z), o, g.y), o, g.x);   // f
+                            gs[e] = 0.0f;
+                            if constexpr (kHasStd) {
+                                gs[e] = __builtin_fmaf(__builtin_fmaf(3.0f * g.w, o, g.z + g.z), o, g.y);   // df / dcode
+                                if constexpr (CLAMP) gs[e] = above ? 0.0f : gs[e];
+                            }
                         } else if constexpr (kLut) {
                             const float2 g = *reinterpret_cast<const float2 *>(lds + lds_entry_address(tf[e], rowc[e]));
                             ga[e] = g.x;
@@ -921,7 +966,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 #pragma unroll
                 for (int e = 0; e < V; ++e) {  // stage B: f, weight, running sums
                     const float px = pxv[e];
-                    const float lin = kLookup ? ga[e] : kLut ? __builtin_fmaf(gs[e], kRough ? pxl[e] : px, ga[e]) : px * a.inv_max_code;
+                    const float lin = (kLookup || kCat) ? ga[e] : kLut ? __builtin_fmaf(gs[e], kRough ? pxl[e] : px, ga[e]) : px * a.inv_max_code;
                     const float yd = __builtin_fmaf(lin, it, -p[e]);  // y_n - p
                     if constexpr (kGauss) {
                         const float dk = dkv[e], w = wv[e];
@@ -1200,6 +1245,7 @@ static int launch_pivot_grid(const MergeArgs &a, const PivotArgs &x, size_t lds,
     return hipGetLastError() == hipSuccess ? CT_OK : CT_ERR_LAUNCH;
 }
 
+#if CT_MERGE_PART != 1
 template <typename T, int V, int INTERP, int WEIGHT, int STD, bool CLAMP>
 static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
 {
@@ -1208,9 +1254,9 @@ static int launch_pivot(const MergeArgs &a, PivotArgs x, hipStream_t stream)
         return CT_ERR_NO_GRADIENT_PATH;  // (refused by ct_hdr_merge_batch before it gets here)
     } else {
         x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);  // a.q_count is a multiple of V
-        constexpr bool kTable = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;
+        constexpr bool kTable = INTERP != CT_INTERP_NONE;
         constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && CT_PIVOT_TYPED_LOAD && sizeof(T) == 2 && V == 4) ? CT_PIVOT_WEIGHT : 0;
-        size_t lds = (kTable ? (size_t)a.channels * x.n_entries * (kWV == 2 ? 16 : 8) : 0) +
+        size_t lds = (kTable ? (size_t)a.channels * x.n_entries * ((kWV == 2 || INTERP == CT_INTERP_CATMULL) ? 16 : 8) : 0) +
                      2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
         x.rgb252 = 0;
         if constexpr (V == 4 && CT_PIVOT_TYPED_LOAD) {
@@ -1261,12 +1307,18 @@ static int dispatch_pivot_interp(const MergeArgs &a, const PivotArgs &x, int int
         if (interp == CT_INTERP_LOOKUP)
             return gauss ? dispatch_pivot_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
                          : dispatch_pivot_std<T, V, CT_INTERP_LOOKUP, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
+        if (interp == CT_INTERP_CATMULL)
+            return gauss ? dispatch_pivot_std<T, V, CT_INTERP_CATMULL, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
+                         : dispatch_pivot_std<T, V, CT_INTERP_CATMULL, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
     }
     // no model: no table, nothing to clamp
     return gauss ? dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_GAUSS, false>(a, x, std_mode, s)
                  : dispatch_pivot_std<T, V, CT_INTERP_NONE, CT_WEIGHT_NONE, false>(a, x, std_mode, s);
 }
 
+#endif  // CT_MERGE_PART != 1
+
+#if CT_MERGE_PART != 0
 // ---- several batches per launch (MULTI): packets of kPivotV only, state-carrying instantiation ----
 template <typename T, int INTERP, int WEIGHT, int STD, bool CLAMP>
 static int launch_pivot_multi(const MergeArgs &a, PivotArgs x, hipStream_t stream)
@@ -1279,9 +1331,9 @@ static int launch_pivot_multi(const MergeArgs &a, PivotArgs x, hipStream_t strea
     } else {
         constexpr int V = kPivotV;
         x.n_tiles = (a.q_count + (uint32_t)(kBlock * V) - 1) / (uint32_t)(kBlock * V);
-        constexpr bool kTable = INTERP == CT_INTERP_LINEAR || INTERP == CT_INTERP_LOOKUP;
+        constexpr bool kTable = INTERP != CT_INTERP_NONE;
         constexpr int kWV = (INTERP == CT_INTERP_LINEAR && WEIGHT == CT_WEIGHT_GAUSS && sizeof(T) == 2) ? CT_PIVOT_WEIGHT : 0;
-        const size_t lds = (kTable ? (size_t)a.channels * x.n_entries * (kWV == 2 ? 16 : 8) : 0) +
+        const size_t lds = (kTable ? (size_t)a.channels * x.n_entries * ((kWV == 2 || INTERP == CT_INTERP_CATMULL) ? 16 : 8) : 0) +
                            2 * sizeof(float) * (size_t)a.batch + (kWV == 1 ? (size_t)(65536 >> CT_PIVOT_WT_SHIFT) * 8 : 0);
         if (lds > 160 * 1024) return CT_ERR_TOO_LARGE;
         return launch_pivot_grid<merge_pivot_kernel<T, V, INTERP, WEIGHT, STD, false, CLAMP, true>>(a, x, lds, stream);
@@ -1310,10 +1362,28 @@ static int dispatch_multi_interp(const MergeArgs &a, const PivotArgs &x, int int
     if (interp == CT_INTERP_LOOKUP)
         return gauss ? dispatch_multi_std<T, CT_INTERP_LOOKUP, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
                      : dispatch_multi_std<T, CT_INTERP_LOOKUP, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
+    if (interp == CT_INTERP_CATMULL)
+        return gauss ? dispatch_multi_std<T, CT_INTERP_CATMULL, CT_WEIGHT_GAUSS, CLAMP>(a, x, std_mode, s)
+                     : dispatch_multi_std<T, CT_INTERP_CATMULL, CT_WEIGHT_NONE, CLAMP>(a, x, std_mode, s);
     return gauss ? dispatch_multi_std<T, CT_INTERP_NONE, CT_WEIGHT_GAUSS, false>(a, x, std_mode, s)
                  : dispatch_multi_std<T, CT_INTERP_NONE, CT_WEIGHT_NONE, false>(a, x, std_mode, s);
 }
 
+
+// The several-batches launch of ct_hdr_merge_batches (defined in the CT_MERGE_PART 1 translation unit).
+int merge_pivot_multi(const MergeArgs &a, const PivotArgs &px, int dtype, bool clamp, int interp, int weight_mode, int std_mode,
+                      hipStream_t s)
+{
+    if (dtype == CT_DTYPE_U8) return dispatch_multi_interp<uint8_t, false>(a, px, interp, weight_mode, std_mode, s);
+    return clamp ? dispatch_multi_interp<uint16_t, true>(a, px, interp, weight_mode, std_mode, s)
+                 : dispatch_multi_interp<uint16_t, false>(a, px, interp, weight_mode, std_mode, s);
+}
+#else
+int merge_pivot_multi(const MergeArgs &a, const PivotArgs &px, int dtype, bool clamp, int interp, int weight_mode, int std_mode,
+                      hipStream_t s);
+#endif  // CT_MERGE_PART != 0
+
+#if CT_MERGE_PART != 1
 // CLAMP (codes above max_code exist: max_code below the container's range) costs one v_min per sample, so it is its own
 // instantiation for uint16 packets; the one-element launch of a ragged tail always carries it (its cost is irrelevant);
 // uint8 packets with max_code < 255 are left to the generic kernel (pivot_eligible).
@@ -1455,7 +1525,11 @@ static int merge_typed(MergeArgs a, uint32_t Q, int interp, int weight_mode, int
     return rc;
 }
 
+#endif  // CT_MERGE_PART != 1
+
 }  // namespace ct
+
+#if CT_MERGE_PART != 1
 
 // Host check that fma(u, hi, u*lo) == u / max_code for every code (see NormConst in ct_device.hpp).
 extern "C" int ct_norm_constants(float max_code, float *hi, float *lo);
@@ -1484,7 +1558,8 @@ static bool pivot_eligible(int32_t dtype, float max_code, int interp, int n_poin
     const int dtype_max = dtype == CT_DTYPE_U8 ? 255 : 65535;
     if (flags & CT_MERGE_F64_MOMENTS) return false;
     if (!(max_code >= 1.0f) || max_code > (float)dtype_max || floorf(max_code) != max_code) return false;
-    if (interp != CT_INTERP_LINEAR && interp != CT_INTERP_NONE && interp != CT_INTERP_LOOKUP) return false;
+    if (interp < CT_INTERP_LOOKUP || interp > CT_INTERP_NONE) return false;
+    if (interp == CT_INTERP_CATMULL && !CT_PIVOT_TYPED_LOAD) return false;
     const bool need_clamp = interp != CT_INTERP_NONE && max_code < (float)dtype_max;
     if (clamp) *clamp = need_clamp;
     px->step = 1.0f;
@@ -1768,8 +1843,7 @@ extern "C" int ct_hdr_merge_batches(const void *const *stack_devs, const float *
         px.batch_ptr[b] = stack_devs[b];
         px.std_ptr[b] = std_mode == CT_STD_EXPLICIT ? std_devs[b] : nullptr;
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == CT_DTYPE_U8) return dispatch_multi_interp<uint8_t, false>(a, px, interp, weight_mode, std_mode, s);
-    return clamp ? dispatch_multi_interp<uint16_t, true>(a, px, interp, weight_mode, std_mode, s)
-                 : dispatch_multi_interp<uint16_t, false>(a, px, interp, weight_mode, std_mode, s);
+    return merge_pivot_multi(a, px, dtype, clamp, interp, weight_mode, std_mode, static_cast<hipStream_t>(stream));
 }
+
+#endif  // CT_MERGE_PART != 1

@@ -469,10 +469,11 @@ def test_merge_unusual_lut_sizes(dev, n_points, dtype):
     t = 0.001 * 2.0 ** np.arange(n)
     lut = np.stack([np.linspace(0, 1, n_points, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
     for mode in ("linear", "lookup", "catmull"):
-        # LINEAR and LOOKUP on raw codes run the pivoted code-domain kernel for ANY LUT length the host proof accepts
-        # (steps that are not a whole number of codes included); CATMULL and refused lengths the generic pivoted kernel
+        # raw codes run the pivoted code-domain kernel for ANY LUT length the host proof accepts (steps that are not a whole
+        # number of codes included; CATMULL's closed form too since round 3: the interval's cubic in the code offset);
+        # refused lengths the generic pivoted kernel
         name = _kernel_name(dtype, hi - 1, mode, n_points)
-        assert ("merge_pivot_kernel" in name) == (mode != "catmull" and _pivot_proven(hi - 1, n_points, mode == "lookup", hi - 1)), name
+        assert ("merge_pivot_kernel" in name) == _pivot_proven(hi - 1, n_points, mode == "lookup", hi - 1), name
         mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, mode, True)
         mean, std = ops.hdr_merge_batch(torch.from_numpy(codes).to(dev), torch.from_numpy(t), lut=torch.from_numpy(lut).to(dev),
                                         interp=mode, std_mode="multiplier", std_value=0.05, **_closed_form(mode))
@@ -533,7 +534,7 @@ def test_codes_above_max_code_are_clamped_like_the_reference(dev, mode):
     t = 0.001 * 2.0 ** np.arange(n)
     lut = np.stack([np.linspace(0, 1, 256, dtype=np.float32) ** np.float32(p) for p in (1.7, 2.2, 2.7)])
     # Normalize(4095) on uint16: the pivoted code-domain kernel with the clamp (one v_min per sample), not the generic one
-    assert ("merge_pivot_kernel" in _kernel_name("u16", 4095, mode, 256)) == (mode != "catmull")
+    assert "merge_pivot_kernel" in _kernel_name("u16", 4095, mode, 256)
     for part in ([n], [2, 4]):
         mean_o, std_o = oc.hdr_merge(x, x * np.float32(0.05), t, lut, mode, True, part)
         mean, std = _run_partition(ops, torch.from_numpy(codes).to(dev), t, part, dev, lut=torch.from_numpy(lut).to(dev),
@@ -742,9 +743,9 @@ def test_merge_batches_one_launch_equals_one_launch_per_batch(dev, dtype, max_co
 
 
 def test_merge_batches_falls_back_where_one_launch_cannot_run(dev):
-    """Odd plane sizes (no whole packets), float32 pixels, CATMULL without uncertainties (the generic kernel):
-    ct_hdr_merge_batches walks the batches with one launch each -- same results as the explicit loop; with
-    require_one_launch it says so instead."""
+    """Odd plane sizes (no whole packets), float32 pixels, a LUT length the host proof refuses (772 points on uint16: the
+    generic kernel): ct_hdr_merge_batches walks the batches with one launch each -- same results as the explicit loop;
+    with require_one_launch it says so instead."""
     from clair_torch_amd import ops
     rng = np.random.default_rng(5)
     n, c, h, w = 9, 3, 7, 9
@@ -752,10 +753,12 @@ def test_merge_batches_falls_back_where_one_launch_cannot_run(dev):
     lut = torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]).to(dev)
     cases = [(torch.from_numpy(rng.integers(0, 65536, size=(n, c, h, w)).astype(np.uint16)).to(dev), "linear"),
              (torch.from_numpy(rng.random((n, c, 8, 8), dtype=np.float32)).to(dev), "linear"),
-             (torch.from_numpy(rng.integers(0, 65536, size=(n, c, 8, 8)).astype(np.uint16)).to(dev), "catmull")]
+             (torch.from_numpy(rng.integers(0, 65536, size=(n, c, 8, 8)).astype(np.uint16)).to(dev), "linear772")]
+    assert not _pivot_proven(65535, 772, False, 65535)
+    lut772 = torch.stack([torch.linspace(0, 1, 772) ** p for p in (2.2, 2.4, 2.6)]).to(dev)
     for stack, mode in cases:
-        std_mode = "none" if mode == "catmull" else "multiplier"
-        kw = dict(lut=lut, interp=mode, gaussian_weight=True, std_mode=std_mode, std_value=0.05)
+        std_mode = "multiplier"
+        kw = dict(lut=lut772 if mode == "linear772" else lut, interp="linear", gaussian_weight=True, std_mode=std_mode, std_value=0.05)
         parts = [(0, 4), (4, 6), (6, 9)]
         st = ops.MergeState(tuple(stack.shape[1:]), dev, std_mode != "none")
         for k, (a, b) in enumerate(parts):

@@ -2,6 +2,7 @@
 // (csrc/ct_merge.hip is included verbatim) on the C2 shape, interleaved rounds in one process.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/merge_bench.hip \
 //         clair_torch_amd/csrc/ct_merge_exact.hip clair_torch_amd/csrc/ct_api.cpp -o tools/merge_bench
+#define CT_MERGE_PART 2  // both translation units of the product file in one
 #include "../clair_torch_amd/csrc/ct_merge.hip"
 #include <stdio.h>
 #include <stdlib.h>
