@@ -22,6 +22,8 @@ run merge_c2_max4095 --steps 20 --warmup 5 --no-cpu-baseline --max-code 4095
 run merge_c2_f32 --steps 20 --warmup 5 --no-cpu-baseline --input f32
 run merge_c2_lookup --steps 20 --warmup 5 --no-cpu-baseline --interp lookup
 run merge_c2_catmull --steps 20 --warmup 5 --no-cpu-baseline --interp catmull
+run merge_c2_catmull_mean_only --steps 20 --warmup 5 --no-cpu-baseline --interp catmull --std none
+run merge_c2_linear_mean_only --steps 20 --warmup 5 --no-cpu-baseline --std none
 run merge_c5_strong_n1 --steps 10 --warmup 3 --no-cpu-baseline --scaling strong
 run linearize_c4 --workload linearize --steps 200 --warmup 20
 run linearize_c4_bgr --workload linearize --steps 200 --warmup 20 --no-cpu-baseline --layout nhwc_bgr
