@@ -866,8 +866,9 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
 #pragma unroll
             for (int e = 0; e < V; ++e) W[e] = Swy[e] = Saa[e] = Sac[e] = Scc[e] = 0.0f;
 
-            auto run_batch = [&](auto rough_c) {
+            auto run_batch = [&](auto rough_c, auto moments_c) {
             constexpr bool kRough = decltype(rough_c)::value;  // see the staging: exact but slower interval arithmetic
+            constexpr bool kMoments = decltype(moments_c)::value;  // false: sum of weights and weighted sum only (kMeanFirst)
             // one exposure of this thread's V elements
             auto reduce = [&](const CodePk &pk, const Packet<float, V> &sp, uint32_t expo_adr) {
                 const float2 ex = *reinterpret_cast<const float2 *>(lds + expo_adr);  // {1 / t_n, chain factor} of this exposure
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                         const float dk = dkv[e], w = wv[e];
                         W[e] += w;
                         Swy[e] = __builtin_fmaf(w, yd, Swy[e]);
-                        if constexpr (kHasStd) {
+                        if constexpr (kHasStd && kMoments) {
                             float wu = w;
                             if constexpr (STD == CT_STD_MULTIPLIER) wu = w * px;
                             if constexpr (STD == CT_STD_EXPLICIT) wu = w * sp.v[e];
@@ -1037,10 +1038,22 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                 expo_adr += 8u * kRing;
             }
             };
-            if (rough)
-                run_batch(std::true_type{});
-            else
-                run_batch(std::false_type{});
+            // LOOKUP's closed-form variance is the weight path alone, sum a_n^2 (y_n - m)^2: about any pivot that is not the
+            // mean it cancels, and every wavefront of C2 used to repeat its batch (tools/debug/retry_rate.py: 196 608 of
+            // 196 608).  So its first pass computes the mean only (9 instead of 17 instructions per sample) and the second,
+            // about that mean, the moments.
+            constexpr bool kMeanFirst = kLookup && kHasStd;
+            if constexpr (kMeanFirst) {
+                if (pass == 0)
+                    run_batch(std::false_type{}, std::false_type{});
+                else
+                    run_batch(std::false_type{}, std::true_type{});
+            } else {
+                if (rough)
+                    run_batch(std::true_type{}, std::true_type{});
+                else
+                    run_batch(std::false_type{}, std::true_type{});
+            }
 
             // ---- epilogue: WBOMean update (statistics.py:64-109) and the closed-form variance, division-free ----
             bool bad[V];
@@ -1081,6 +1094,7 @@ __global__ __launch_bounds__(kBlock) CT_PIVOT_KERNEL_ATTR void merge_pivot_kerne
                     const float S = __builtin_fmaf(kap * kap, Saa[e], (beta * beta) * Scc[e]);
                     const float upd = __builtin_fmaf(bk + bk, Sac[e], S);
                     if constexpr (kGauss) bad[e] = upd * (0.5f * (kPivotCondLimit + 1.0f)) < S;
+                    if constexpr (kMeanFirst) bad[e] = bad[e] || pass == 0;  // (the first pass had no moments: go on about the mean)
                     var += fmaxf(upd, 0.0f) * sv2;
                 }
                 var_o[e] = var;
