@@ -669,7 +669,7 @@ def test_pivot_kernel_retry_pass_is_taken_and_exact(dev, dtype):
 @pytest.mark.parametrize("dtype,max_code", [("u16", 65535), ("u8", 255), ("u16", 4095)])
 @pytest.mark.parametrize("mode,gauss,std_mode", [("linear", True, "multiplier"), ("linear", True, "explicit"), ("linear", False, "constant"),
                                                  ("linear", True, "none"), (None, True, "multiplier"), ("lookup", True, "constant"),
-                                                 ("lookup", False, "none")])
+                                                 ("lookup", False, "none"), ("catmull", True, "none"), ("catmull", True, "multiplier")])
 def test_merge_batches_one_launch_equals_one_launch_per_batch(dev, dtype, max_code, mode, gauss, std_mode):
     """ct_hdr_merge_batches: several consecutive batches in ONE launch of ct::merge_pivot_kernel, the streaming state in
     registers in between (VERDICT r2 missing #3: the reference's default is batch_size: 4).  Bit for bit what one launch
