@@ -128,6 +128,16 @@ def test_public_api_with_cv_to_torch_transform(dev):
     assert cv_out[0].shape == (20, 28, 3)
     assert torch.equal(cv_out[0].flip(-1).permute(2, 0, 1), ref[0]) and torch.equal(cv_out[1].flip(-1).permute(2, 0, 1), ref[1])
 
+    # reference_order=False through the public API: the closed-form kernels also for CATMULL with uncertainties
+    cat = ICRFModelDirect(icrf=torch.stack([torch.linspace(0, 1, 256) ** p for p in (2.2, 2.4, 2.6)]),
+                          interpolation_mode=InterpMode.CATMULL).to(dev)
+    slow_cat = compute_hdr_image(DataLoader(ds_p, batch_size=3, collate_fn=custom_collate), "cuda", cat,
+                                 weight_fn=gaussian_value_weights, gpu_transforms=norm)
+    fast_cat = compute_hdr_image(DataLoader(ds_p, batch_size=3, collate_fn=custom_collate), "cuda", cat,
+                                 weight_fn=gaussian_value_weights, gpu_transforms=norm, reference_order=False)
+    assert torch.allclose(fast_cat[0], slow_cat[0], rtol=1e-5) and not torch.equal(fast_cat[1], slow_cat[1])
+    assert float((fast_cat[1] - slow_cat[1]).norm() / slow_cat[1].norm()) < 2e-5
+
     class Identity(BaseTransform):
         def __call__(self, x):
             return x
